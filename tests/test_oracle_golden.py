@@ -1,0 +1,100 @@
+"""Pin the CPU oracle (oracle/swin_fusion_oracle.py) against golden vectors captured from
+the real reference (oracle/make_golden.py).  Bar: <=1e-5 relative (fp32 thread-order noise
+of the reference itself is ~3e-7..3e-6 abs)."""
+import json
+import os
+
+import pytest
+import torch
+
+from oracle import swin_fusion_oracle as O
+from swin_unet_image_fusion_amd.config import CONFIGS
+from tests import golden_util as G
+
+TOL = 1e-5
+
+
+def _check(got, exp, tol=TOL):
+    assert got.shape == exp.shape
+    l2, mx = G.rel_err(got, exp)
+    assert l2 <= tol and mx <= tol, (l2, mx)
+
+
+@pytest.mark.parametrize("name", G.cases("window_attention"))
+def test_window_attention(name):
+    meta, arr = G.load(name)
+    c = meta["ctor"]
+    sd = G.recipe_state(meta)
+    q = G.randn(meta["in_shape"], meta["seed_q"])
+    kv = G.randn(meta["in_shape"], meta["seed_kv"]) if c["use_cross_attention"] else q
+    out = O.window_attention(sd, "", q, kv, kv, num_heads=c["num_heads"], dims_per_head=c["dims_per_head"],
+                             window_size=tuple(c["window_size"]), use_cyclic_shift=c["use_cyclic_shift"])
+    _check(out, arr["expected"])
+
+
+@pytest.mark.parametrize("name", G.cases("basic_block"))
+def test_basic_block(name):
+    meta, arr = G.load(name)
+    c = meta["ctor"]
+    sd = G.recipe_state(meta)
+    x, y = G.randn(meta["in_shape"], meta["seed_x"]), G.randn(meta["in_shape"], meta["seed_y"])
+    ox, oy = O.basic_block(sd, "", x, y, cross=c["use_cross_attr"], shift=c["use_cyclic_shift"],
+                           num_heads=c["num_heads"], dims_per_head=c["dims_per_head"],
+                           window_size=tuple(c["window_size"]))
+    _check(ox, arr["expected_x"]); _check(oy, arr["expected_y"])
+
+
+@pytest.mark.parametrize("name", G.cases("self_and_cross_block_pair"))
+def test_self_and_cross_block_pair(name):
+    meta, arr = G.load(name)
+    c = meta["ctor"]
+    sd = G.recipe_state(meta)
+    x, y = G.randn(meta["in_shape"], meta["seed_x"]), G.randn(meta["in_shape"], meta["seed_y"])
+    ox, oy = O.self_and_cross_block_pair(sd, "", x, y, num_heads=c["num_heads"], dims_per_head=c["dims_per_head"],
+                                         window_size=tuple(c["window_size"]))
+    _check(ox, arr["expected_x"]); _check(oy, arr["expected_y"])
+
+
+@pytest.mark.parametrize("name", G.cases("patch_layer"))
+def test_patch_layer(name):
+    meta, arr = G.load(name)
+    sd = G.recipe_state(meta)
+    x, y = G.randn(meta["in_shape"], meta["seed_x"]), G.randn(meta["in_shape"], meta["seed_y"])
+    ox, oy = O.patch_layer(sd, "", x, y, encoder=meta["encoder"], merging_size=(2, 2))
+    _check(ox, arr["expected_x"]); _check(oy, arr["expected_y"])
+
+
+@pytest.mark.parametrize("name", G.cases("padding"))
+def test_padding(name):
+    meta, arr = G.load(name)
+    x, y = G.randn(meta["in_shape"], meta["seed_x"]), G.randn(meta["in_shape"], meta["seed_y"])
+    px, pad = O.pad_to_multiple(x, tuple(meta["window"]))
+    py, _ = O.pad_to_multiple(y, tuple(meta["window"]))
+    assert torch.equal(px, arr["padded_x"]) and torch.equal(py, arr["padded_y"])
+    assert torch.equal(O.crop_padding(px, pad), x)
+
+
+_SLOW = {"model_win16_512"}
+
+
+@pytest.mark.parametrize("name", G.cases("model"))
+def test_model(name):
+    meta, arr = G.load(name)
+    sd = G.recipe_state(meta)
+    ir, vis = G.model_inputs(meta)
+    with torch.no_grad():
+        out = O.model_forward(sd, CONFIGS[meta["config"]], ir, vis)
+    _check(out, arr["expected"])
+
+
+def test_config1_literal_raises_like_reference():
+    """BASELINE config 1 as literally written (128x128, win 8, 5 stages) raises in the
+    reference (reflect pad 4 on a 4x4 map, a006:128); the oracle raises the same class."""
+    with open(os.path.join(G.GOLDEN, "config1_literal_error.json")) as f:
+        rec = json.load(f)
+    assert rec["raises"] == "RuntimeError"
+    meta = dict(weight_seed=0, flavor="default", keys_file="state_keys_win8.json")
+    sd = G.recipe_state(meta)
+    ir, vis = G.model_inputs(dict(in_shape=rec["in_shape"], seed_ir=1, seed_vis=2))
+    with pytest.raises(RuntimeError):
+        O.model_forward(sd, CONFIGS["win8"], ir, vis)
