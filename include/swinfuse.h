@@ -1,0 +1,223 @@
+/*
+ * swinfuse.h — C-ABI of the MI355X (gfx950) Swin-UNet image-fusion forward library.
+ *
+ * The reference (RainbowZL0/swin-unet-image-fusion) has no FFI layer: its boundary is the
+ * Python nn.Module API.  This header is the boundary a maintainer binds underneath that API
+ * (ctypes stub in INTEGRATION.md).  Each entry point names the reference interface it
+ * replaces (file:line relative to the reference root).
+ *
+ * Conventions
+ *  - extern "C", plain pointers and sizes, no C++/torch types.
+ *  - All tensors are DEVICE pointers, fp32, **NHWC** ("token-major": [B][H][W][C]) unless a
+ *    function says NCHW.  (B,1,H,W) NCHW and NHWC coincide, so the whole-model entry takes the
+ *    reference's input/output tensors as they are.
+ *  - The library never allocates, frees or retains device memory: weights and workspaces are
+ *    borrowed for the duration of a call.  Workspace sizes come from the
+ *    *_workspace_bytes queries.
+ *  - Every function enqueues on the caller's stream (hipStream_t passed as void*), never
+ *    synchronises, and is safe to capture into a hipGraph.
+ *  - Return value: 0 = SWF_OK, negative = swf_status.  Nothing throws or aborts.
+ *    swf_last_error_string() gives a thread-local description of the last failure.
+ *  - Only the eval()/no_grad forward is provided (dropout p=0 -> identity, BatchNorm running
+ *    statistics).
+ */
+#ifndef SWINFUSE_H
+#define SWINFUSE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWF_VERSION_MAJOR 0
+#define SWF_VERSION_MINOR 1
+
+typedef void* swf_stream_t; /* hipStream_t */
+
+typedef enum swf_status {
+    SWF_OK = 0,
+    SWF_ERR_NULL = -1,        /* required pointer is NULL */
+    SWF_ERR_BAD_SHAPE = -2,   /* sizes inconsistent (e.g. map not a multiple of the window; einops error in the reference) */
+    SWF_ERR_PAD = -3,         /* reflect pad >= dimension (torch RuntimeError at a006_PaddingOperation.py:128) */
+    SWF_ERR_UNSUPPORTED = -4, /* configuration outside what the kernels cover */
+    SWF_ERR_WORKSPACE = -5,   /* workspace too small */
+    SWF_ERR_HIP = -6          /* a HIP launch failed */
+} swf_status;
+
+/* Arithmetic mode of the window-attention contractions and linear layers.
+ *  FP32 : every contraction in exact fp32 (f32-input MFMA == fmaf chain; VALU attention).
+ *  FAST : fused window kernels — linear layers as split-bf16 (bf16x3, fp32-grade) MFMA,
+ *         QK^T in bf16 MFMA, P.V in fp16 MFMA; LayerNorm statistics, softmax, residual
+ *         stream and all accumulators stay fp32.  Shapes the fused kernels do not cover
+ *         fall back to FP32 kernels (never to the host). */
+typedef enum swf_precision { SWF_PREC_FP32 = 0, SWF_PREC_FAST = 1 } swf_precision;
+
+typedef struct swf_linear { const float* weight; /* [out][in] row-major (nn.Linear / 1x1 Conv2d) */
+                            const float* bias;   /* [out] or NULL */ } swf_linear;
+typedef struct swf_norm   { const float* gamma; const float* beta; } swf_norm; /* LayerNorm over C, eps 1e-5 */
+
+/* ---- WindowAttention (a001_WindowAttention.py:9-20 ctor, :448-474 forward) ---------------- */
+typedef struct swf_attn_desc {
+    int32_t channels;      /* in_out_dims */
+    int32_t heads;         /* num_heads */
+    int32_t head_dim;      /* dims_per_head (heads*head_dim need not equal channels) */
+    int32_t win_h, win_w;  /* window_size */
+    int32_t shift;         /* use_cyclic_shift: roll by (-win_h/2,-win_w/2), mask = -1e10 (a001:217-315) */
+} swf_attn_desc;
+
+typedef struct swf_attn_params {
+    swf_linear q, k, v;        /* q_for_heads / k_for_heads / v_for_heads: [heads*head_dim][channels] */
+    swf_linear proj;           /* linear_projection: [channels][heads*head_dim] */
+    const float* bias_table;   /* relative_position_bias_table [(2*win_h-1)][(2*win_w-1)], shared by all heads (a001:72-82) */
+} swf_attn_params;
+
+/* out = WindowAttention(q, k, v) [+ residual if non-NULL].  q,k,v,out,residual: [B][H][W][C].
+ * H,W must be multiples of the window (SWF_ERR_BAD_SHAPE otherwise). */
+int swf_window_attention_fwd(const swf_attn_desc* desc, const swf_attn_params* p,
+                             const float* q, const float* k, const float* v, const float* residual,
+                             float* out, int32_t B, int32_t H, int32_t W,
+                             void* workspace, size_t workspace_bytes, swf_stream_t stream);
+size_t swf_window_attention_workspace_bytes(const swf_attn_desc* desc, int32_t B, int32_t H, int32_t W);
+
+/* ---- BasicBlock (a005_BasicBlock.py:127-145) and its two halves ---------------------------- */
+typedef struct swf_block_desc {
+    swf_attn_desc attn;
+    int32_t hidden;        /* mlp_hidden_dims */
+    int32_t cross;         /* use_cross_attr: x'=WA_x(q=x,k=y,v=y), y'=WA_y(q=y,k=x,v=x) (a002_AutoPathWinAtt.py:67-82) */
+    int32_t precision;     /* swf_precision */
+} swf_block_desc;
+
+typedef struct swf_block_stream_params {   /* one modality stream of one BasicBlock */
+    swf_norm ln1;              /* stage_1.norm_layer_{1|2}  (a004_AddAndLayerNormWithOtherModule.py:16-18) */
+    swf_attn_params attn;      /* auto_path_win_att.window_attention_{x|y} */
+    swf_norm ln2;              /* stage_2.norm_layer_{1|2} */
+    swf_linear fc1, fc2;       /* auto_path_mlp.mlp_{x|y}_1 [hidden][C], mlp_{x|y}_2 [C][hidden]; ELU(alpha=1) between (a003_AutoPathMLP.py:21-44) */
+} swf_block_stream_params;
+
+/* stage_1 of a BasicBlock for both streams: out = in + Attention(LN(in), ...) (a004:29-38 with
+ * other_module = AutoPathWinAtt a002:58-82).  py / y_* may be NULL for a single-path block. */
+int swf_attn_halfblock_fwd(const swf_block_desc* desc, const swf_block_stream_params* px,
+                           const swf_block_stream_params* py,
+                           const float* x_in, const float* y_in, float* x_out, float* y_out,
+                           int32_t B, int32_t H, int32_t W,
+                           void* workspace, size_t workspace_bytes, swf_stream_t stream);
+/* stage_2: out = in + MLP(LN(in)) per stream (a004:29-38 with other_module = AutoPathMLP a003:46-50). */
+int swf_mlp_halfblock_fwd(const swf_block_desc* desc, const swf_block_stream_params* px,
+                          const swf_block_stream_params* py,
+                          const float* x_in, const float* y_in, float* x_out, float* y_out,
+                          int32_t B, int32_t H, int32_t W,
+                          void* workspace, size_t workspace_bytes, swf_stream_t stream);
+/* whole BasicBlock.forward(x, y) (a005:127-145); x_out/y_out may alias x_in/y_in. */
+int swf_basic_block_fwd(const swf_block_desc* desc, const swf_block_stream_params* px,
+                        const swf_block_stream_params* py,
+                        const float* x_in, const float* y_in, float* x_out, float* y_out,
+                        int32_t B, int32_t H, int32_t W,
+                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
+size_t swf_basic_block_workspace_bytes(const swf_block_desc* desc, int32_t B, int32_t H, int32_t W);
+
+/* SelfAndCrossBlockPair.forward (a012_SelfAndCrossBlockPair.py:70-78): four BasicBlocks in the
+ * order self/normal, self/shifted, cross/normal, cross/shifted (a009:90-109).  `desc` gives the
+ * shared dims; shift/cross flags inside it are ignored.  px[4], py[4]. */
+int swf_block_pair4_fwd(const swf_block_desc* desc, const swf_block_stream_params* px,
+                        const swf_block_stream_params* py,
+                        const float* x_in, const float* y_in, float* x_out, float* y_out,
+                        int32_t B, int32_t H, int32_t W,
+                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
+/* ---- PatchMergingAndLinearLayer (a011_PatchOperation.py:244-264) + MyPadding (a006:167-187) -- */
+typedef struct swf_patch_params { swf_linear conv; /* mlp_layer_{x|y}: 1x1 conv */ swf_norm ln; /* layer_norm_{x|y} */ } swf_patch_params;
+
+/* Encoder stage front: reflect-pad in (H,W) bottom/right to a multiple of (merge_h,merge_w)
+ * (a006:122-131), space-to-depth with channel order (ph*merge_w+pw)*Cin+c (a011:87-93), 1x1 conv
+ * 4Cin->Cout, LayerNorm(Cout), ELU (a011:236-239), then reflect-pad the merged map to a multiple
+ * of (win_h,win_w).  in: [B][H][W][Cin]; out: [B][Ho][Wo][Cout] with Ho,Wo from swf_merge_out_shape.
+ * SWF_ERR_PAD when a reflect pad is >= the dimension it pads (the reference raises RuntimeError). */
+int swf_patch_merge_fwd(const swf_patch_params* p, const float* in, float* out,
+                        int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                        int32_t merge_h, int32_t merge_w, int32_t win_h, int32_t win_w,
+                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
+int swf_merge_out_shape(int32_t H, int32_t W, int32_t merge_h, int32_t merge_w, int32_t win_h, int32_t win_w,
+                        int32_t* Hm, int32_t* Wm, int32_t* Ho, int32_t* Wo);
+
+/* Decoder stage back: crop the window padding (in is [B][Hp][Wp][Cin], valid part Hm x Wm,
+ * a006:143-146), 1x1 conv Cin->mh*mw*Cout, LayerNorm over mh*mw*Cout, depth-to-space (a011:111-117),
+ * ELU (order a011:241), crop to (Hout,Wout) (undo of the merge padding), then optionally add
+ * `skip` [B][Hout][Wout][Cout] (the U-Net skip add that precedes the next decoder stage,
+ * a013_ModelDefinition.py:222-225). */
+int swf_patch_unmerge_fwd(const swf_patch_params* p, const float* in, const float* skip, float* out,
+                          int32_t B, int32_t Hp, int32_t Wp, int32_t Hm, int32_t Wm, int32_t Cin, int32_t Cout,
+                          int32_t merge_h, int32_t merge_w, int32_t Hout, int32_t Wout,
+                          void* workspace, size_t workspace_bytes, swf_stream_t stream);
+size_t swf_patch_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout,
+                                 int32_t merge_h, int32_t merge_w, int32_t win_h, int32_t win_w, int32_t encoder);
+
+/* ---- final fusion head (a013:126-152): cat -> conv kxk reflect -> BatchNorm2d(eval) -> ELU -> conv kxk reflect */
+typedef struct swf_head_params {
+    const float* conv1_w; const float* conv1_b;   /* final_layer.0: [2][2][k][k], [2] */
+    const float* bn_gamma; const float* bn_beta; const float* bn_mean; const float* bn_var; /* final_layer.1, eps 1e-5 */
+    const float* conv2_w; const float* conv2_b;   /* final_layer.3: [1][2][k][k], [1] */
+} swf_head_params;
+/* x,y,out: [B][H][W] (single channel).  tmp workspace: 2*B*H*W floats. */
+int swf_final_head_fwd(const swf_head_params* p, const float* x, const float* y, float* out,
+                       int32_t B, int32_t H, int32_t W, int32_t ksize,
+                       void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
+/* ---- token-level pieces used by the inner reference modules ------------------------------------ */
+/* out[tokens][n_out] = act(in[tokens][n_in] . W^T + b) (+ residual); act 0 = none, 1 = ELU(alpha=1).
+ * nn.Linear (a001:42-61) and 1x1 nn.Conv2d on NHWC tokens (a003:21-22, a011:60-63).  Exact fp32. */
+int swf_linear_fwd(const swf_linear* lin, const float* in, const float* residual, float* out,
+                   int64_t tokens, int32_t n_in, int32_t n_out, int32_t act, swf_stream_t stream);
+/* my_layer_norm (a004:54-72): LayerNorm over C of [tokens][C], eps 1e-5; elu != 0 applies ELU after. */
+int swf_layernorm_fwd(const swf_norm* ln, const float* in, float* out, int64_t tokens, int32_t C, int32_t elu,
+                      swf_stream_t stream);
+/* MyPadding encoder side (a006:122-131): reflect-pad bottom/right by (pad_h,pad_w); [B][H][W][C] ->
+ * [B][H+pad_h][W+pad_w][C].  An NCHW tensor is passed as B*C maps with C=1.  SWF_ERR_PAD if pad >= dim. */
+int swf_reflect_pad_fwd(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C,
+                        int32_t pad_h, int32_t pad_w, swf_stream_t stream);
+/* MyPadding decoder side (a006:133-146): top-left crop [B][Hp][Wp][C] -> [B][H][W][C]. */
+int swf_crop_fwd(const float* in, float* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t C,
+                 swf_stream_t stream);
+
+/* ---- layout helpers for the NCHW module API (a007_utils.py:7-26 are the reference's permutes) */
+int swf_nchw_to_nhwc(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W, swf_stream_t stream);
+int swf_nhwc_to_nchw(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W, swf_stream_t stream);
+
+/* ---- whole model: MyModel.forward(in_x, in_y) (a013:209-230) -------------------------------- */
+#define SWF_MAX_LEVELS 8
+typedef struct swf_model_desc {
+    int32_t levels;                      /* len(in_dims_list) */
+    int32_t in_dims[SWF_MAX_LEVELS];     /* in_dims_list  (a013:22) */
+    int32_t out_dims[SWF_MAX_LEVELS];    /* out_dims_list (a013:23) */
+    int32_t heads;                       /* att_num_heads */
+    int32_t head_dim[SWF_MAX_LEVELS];    /* floor(out_dims[j]*att_dims_per_head_ratio) (a013:174,191) */
+    int32_t mlp_ratio;                   /* mlp_hidden_dims_ratio: encoder hidden = out_dims[j]*ratio (a013:177), decoder hidden = in_dims[j]*ratio (a013:196) */
+    int32_t win_h, win_w, merge_h, merge_w;
+    int32_t head_ksize;                  /* final_conv_layer_kernel_size */
+    int32_t precision;                   /* swf_precision */
+} swf_model_desc;
+
+/* The weights live in ONE fp32 device arena whose layout the library defines.  Parameter i has
+ * the reference's canonical state_dict key (e.g.
+ * "encoder_list.0.3.self_att_block.normal_window_block.auto_path_win_att.window_attention_x.q_for_heads.weight"),
+ * an element offset into the arena and an element count; the host copies each tensor there once. */
+int32_t swf_model_param_count(const swf_model_desc* desc);
+int swf_model_param_info(const swf_model_desc* desc, int32_t index, char* name_buf, size_t name_buf_len,
+                         int64_t* offset_elems, int64_t* numel);
+int64_t swf_model_arena_elems(const swf_model_desc* desc);
+size_t swf_model_workspace_bytes(const swf_model_desc* desc, int32_t B, int32_t H, int32_t W);
+/* ir, vis, out: [B][1][H][W] == [B][H][W][1] fp32.  out is NOT clamped (callers clamp: a016:153, a017:83). */
+int swf_model_forward(const swf_model_desc* desc, const float* arena, const float* ir, const float* vis,
+                      float* out, int32_t B, int32_t H, int32_t W,
+                      void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
+/* ---- misc ------------------------------------------------------------------------------------ */
+int swf_version(void);                     /* major*1000 + minor */
+const char* swf_last_error_string(void);   /* thread-local, never NULL */
+const char* swf_status_string(int status);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWINFUSE_H */

@@ -1,0 +1,482 @@
+// Exact-fp32 kernel tier for gfx950 (MI355X): covers every shape the reference modules accept
+// (any C, heads, head_dim <= 64, any window, ragged maps through reflect pad / crop).
+// Contractions run on the f32-input MFMA (v_mfma_f32_16x16x4_f32: bit-identical to an fmaf
+// chain, runs at the fp32 vector peak and leaves the VALU free); attention is a per-lane-query
+// two-pass softmax with the window's K/V tile staged in LDS.
+// The fused fast tier (kernels_window.hip) replaces these for the model's standard shapes.
+#include "kernels_generic.h"
+
+#include <algorithm>
+
+namespace swf {
+
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+__device__ __forceinline__ float elu1(float v) { return v > 0.f ? v : expm1f(v); }
+
+// ------------------------------------------------------------------------------------------
+// GEMM: out[M][N] = act(A[M][K] . W[N][K]^T + bias) (+res)
+// 64x64 output tile per 256-thread workgroup, 4 waves as 2x2, each wave 2x2 MFMA tiles of 16x16,
+// K staged 16 at a time through LDS (row stride 20 floats: 16-B aligned float4 stores, 2-way
+// worst-case bank conflict on the b32 fragment reads).
+// ------------------------------------------------------------------------------------------
+constexpr int GBM = 64, GBN = 64, GBK = 16, GLD = GBK + 4;
+
+__global__ __launch_bounds__(256) void gemm_f32_kernel(GemmBatch batch, int M, int N, int K, int lda, int ldo,
+                                                        int act, int vecA, int vecW) {
+    const GemmProb pr = batch.p[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) float As[GBM * GLD];
+    __shared__ __attribute__((aligned(16))) float Ws[GBN * GLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int brow = blockIdx.x * GBM, bcol = blockIdx.y * GBN;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    const int lr = tid >> 2, lk = (tid & 3) * 4;
+    const int64_t arow = (int64_t)(brow + lr) * lda;
+    const int64_t wrow = (int64_t)(bcol + lr) * K;
+    const bool a_in = (brow + lr) < M, w_in = (bcol + lr) < N;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    for (int k0 = 0; k0 < K; k0 += GBK) {
+        const int gk = k0 + lk;
+        float4 va = make_float4(0.f, 0.f, 0.f, 0.f), vw = va;
+        if (a_in) {
+            if (vecA && gk < K) va = *reinterpret_cast<const float4*>(pr.A + arow + gk);
+            else {
+                if (gk + 0 < K) va.x = pr.A[arow + gk + 0];
+                if (gk + 1 < K) va.y = pr.A[arow + gk + 1];
+                if (gk + 2 < K) va.z = pr.A[arow + gk + 2];
+                if (gk + 3 < K) va.w = pr.A[arow + gk + 3];
+            }
+        }
+        if (w_in) {
+            if (vecW && gk < K) vw = *reinterpret_cast<const float4*>(pr.W + wrow + gk);
+            else {
+                if (gk + 0 < K) vw.x = pr.W[wrow + gk + 0];
+                if (gk + 1 < K) vw.y = pr.W[wrow + gk + 1];
+                if (gk + 2 < K) vw.z = pr.W[wrow + gk + 2];
+                if (gk + 3 < K) vw.w = pr.W[wrow + gk + 3];
+            }
+        }
+        __syncthreads();  // previous k-step's fragment reads are done
+        *reinterpret_cast<float4*>(&As[lr * GLD + lk]) = va;
+        *reinterpret_cast<float4*>(&Ws[lr * GLD + lk]) = vw;
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < GBK / 4; ++kk) {
+            float a[2], b[2];
+#pragma unroll
+            for (int m = 0; m < 2; ++m) a[m] = As[(wr * 32 + m * 16 + fr) * GLD + kk * 4 + fq];
+#pragma unroll
+            for (int n = 0; n < 2; ++n) b[n] = Ws[(wc * 32 + n * 16 + fr) * GLD + kk * 4 + fq];
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], b[n], acc[m][n], 0, 0, 0);
+        }
+    }
+    // C/D map of the 16x16 MFMA: col = lane & 15, row = (lane >> 4) * 4 + reg
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = bcol + wc * 32 + n * 16 + fr;
+            if (col >= N) continue;
+            const float bv = pr.bias ? pr.bias[col] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = brow + wr * 32 + m * 16 + fq * 4 + j;
+                if (row >= M) continue;
+                float v = acc[m][n][j] + bv;
+                if (act == 1) v = elu1(v);
+                const int64_t o = (int64_t)row * ldo + col;
+                if (pr.res) v = pr.res[o] + v;
+                pr.out[o] = v;
+            }
+        }
+}
+
+int launch_gemm_f32(const GemmBatch& batch, int nprob, int M, int N, int K, int lda, int ldo, int act,
+                    hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return fail(SWF_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", M, N, K);
+    int vecA = (lda % 4 == 0) && (K % 4 == 0), vecW = (K % 4 == 0);
+    for (int i = 0; i < nprob; ++i) {
+        if (reinterpret_cast<uintptr_t>(batch.p[i].A) % 16) vecA = 0;
+        if (reinterpret_cast<uintptr_t>(batch.p[i].W) % 16) vecW = 0;
+    }
+    dim3 grid(cdiv(M, GBM), cdiv(N, GBN), nprob);
+    hipLaunchKernelGGL(gemm_f32_kernel, grid, dim3(256), 0, stream, batch, M, N, K, lda, ldo, act, vecA, vecW);
+    return check_launch("gemm_f32");
+}
+
+// ------------------------------------------------------------------------------------------
+// LayerNorm over C per token.  L lanes (power of two) cooperate on a token.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void layernorm_kernel(LnBatch batch, int64_t tokens, int C, int L, int elu) {
+    const LnProb pr = batch.p[blockIdx.y];
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tok = gt / L;
+    const int sub = (int)(gt % L);
+    const bool live = tok < tokens;
+    const float* x = pr.in + (live ? tok : 0) * C;
+    float s = 0.f;
+    if (live) for (int c = sub; c < C; c += L) s += x[c];
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float v = 0.f;
+    if (live) for (int c = sub; c < C; c += L) { const float d = x[c] - mean; v += d * d; }
+    for (int o = L >> 1; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    const float rstd = 1.0f / sqrtf(v / (float)C + 1e-5f);
+    if (!live) return;
+    float* y = pr.out + tok * C;
+    for (int c = sub; c < C; c += L) {
+        float r = (x[c] - mean) * rstd * pr.gamma[c] + pr.beta[c];
+        if (elu) r = elu1(r);
+        y[c] = r;
+    }
+}
+
+int launch_layernorm(const LnBatch& batch, int nprob, int64_t tokens, int C, int elu, hipStream_t stream) {
+    int L = 1;
+    while (L < 64 && L * 4 < C) L <<= 1;
+    const int64_t threads = tokens * L;
+    dim3 grid((unsigned)cdiv64(threads, 256), nprob);
+    hipLaunchKernelGGL(layernorm_kernel, grid, dim3(256), 0, stream, batch, tokens, C, L, elu);
+    return check_launch("layernorm");
+}
+
+// ------------------------------------------------------------------------------------------
+// Window attention core (a001:317-355 on windows cut by a001:154-172, shift a001:419-446).
+// One workgroup = one (window, head); one lane = one query token.  K/V rows of the head are
+// staged in LDS zero-padded to DMAX so the inner loops are fully unrolled register code.
+// Two passes over the keys: row max, then exp / sum / P.V — the same order of operations as
+// softmax-then-matmul in the reference.
+// ------------------------------------------------------------------------------------------
+template <int DMAX>
+__global__ void attn_core_kernel(AttnCoreBatch batch, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
+                                 int wh, int ww, int heads, int d, int shift, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AttnCoreProb pr = batch.p[blockIdx.z];
+    const int t = wh * ww;
+    float* Ks = smem;
+    float* Vs = Ks + t * DMAX;
+    float* tab = Vs + t * DMAX;
+    const int tw = 2 * ww - 1, tsz = (2 * wh - 1) * tw;
+    const int nwx = W / ww, nwy = H / wh;
+    const int win = blockIdx.x, head = blockIdx.y;
+    const int b = win / (nwx * nwy), wrem = win % (nwx * nwy);
+    const int wy = wrem / nwx, wx = wrem % nwx;
+    const int sh = shift ? wh / 2 : 0, sw = shift ? ww / 2 : 0;
+    const int tid = threadIdx.x;
+
+    for (int i = tid; i < tsz; i += blockDim.x) tab[i] = pr.bias_table[i];
+    // stage K and V (zero padded to DMAX)
+    for (int e = tid; e < t * DMAX; e += blockDim.x) {
+        const int j = e / DMAX, c = e % DMAX;
+        float kv = 0.f, vv = 0.f;
+        if (c < d) {
+            const int sy = wy * wh + j / ww, sx = wx * ww + j % ww;       // shifted-frame coordinates
+            const int oy = (sy + sh) % H, ox = (sx + sw) % W;            // roll(-s): shifted[y] = orig[(y+s)%H]
+            const int64_t tok = ((int64_t)b * H + oy) * W + ox;
+            kv = pr.K[tok * ldk + head * d + c];
+            vv = pr.V[tok * ldv + head * d + c];
+        }
+        Ks[e] = kv;
+        Vs[e] = vv;
+    }
+    __syncthreads();
+    const int i = tid;
+    if (i >= t) return;
+    const int iy = i / ww, ix = i % ww;
+    const int sy = wy * wh + iy, sx = wx * ww + ix;
+    const int oy = (sy + sh) % H, ox = (sx + sw) % W;
+    const int64_t tok = ((int64_t)b * H + oy) * W + ox;
+    float q[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) q[c] = c < d ? pr.Q[tok * ldq + head * d + c] : 0.f;
+    // region label of a shifted-frame position (a001:222-247)
+    const int my_region = ((sy >= H - wh) + (sy >= H - wh / 2)) * 3 + ((sx >= W - ww) + (sx >= W - ww / 2));
+
+    auto score = [&](int j) -> float {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) dot = fmaf(q[c], Ks[j * DMAX + c], dot);
+        const int jy = j / ww, jx = j % ww;
+        float s = dot * scale + tab[(jy - iy + wh - 1) * tw + (jx - ix + ww - 1)];
+        if (shift) {
+            const int ky = wy * wh + jy, kx = wx * ww + jx;
+            const int kr = ((ky >= H - wh) + (ky >= H - wh / 2)) * 3 + ((kx >= W - ww) + (kx >= W - ww / 2));
+            if (kr != my_region) s = -1e10f;   // assignment, not addition (a001:310)
+        }
+        return s;
+    };
+    float mx = -INFINITY;
+    for (int j = 0; j < t; ++j) mx = fmaxf(mx, score(j));
+    float o[DMAX];
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c) o[c] = 0.f;
+    float l = 0.f;
+    for (int j = 0; j < t; ++j) {
+        const float p = expf(score(j) - mx);
+        l += p;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) o[c] = fmaf(p, Vs[j * DMAX + c], o[c]);
+    }
+    const float inv = 1.0f / l;
+#pragma unroll
+    for (int c = 0; c < DMAX; ++c)
+        if (c < d) pr.O[tok * ldo + head * d + c] = o[c] * inv;
+}
+
+template <int DMAX>
+static int launch_attn_core_t(const AttnCoreBatch& batch, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H,
+                              int W, int wh, int ww, int heads, int d, int shift, hipStream_t stream) {
+    const int t = wh * ww;
+    const size_t lds = ((size_t)2 * t * DMAX + (size_t)(2 * wh - 1) * (2 * ww - 1)) * sizeof(float);
+    if (lds > 160 * 1024) return fail(SWF_ERR_UNSUPPORTED, "attention tile (t=%d, d=%d) needs %zu B of LDS", t, d, lds);
+    if (lds > 64 * 1024) {
+        // raise the dynamic-LDS cap for this instantiation (host-side attribute, no device sync)
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_kernel<DMAX>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+    }
+    const int threads = cdiv(t, 64) * 64;
+    if (threads > 1024) return fail(SWF_ERR_UNSUPPORTED, "window of %d tokens > 1024", t);
+    const int nwin = B * (H / wh) * (W / ww);
+    dim3 grid(nwin, heads, nprob);
+    const float scale = 1.0f / sqrtf((float)d);
+    hipLaunchKernelGGL(attn_core_kernel<DMAX>, grid, dim3(threads), lds, stream, batch, ldq, ldk, ldv, ldo, B, H, W, wh,
+                       ww, heads, d, shift, scale);
+    return check_launch("attn_core");
+}
+
+int launch_attn_core(const AttnCoreBatch& batch, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
+                     int wh, int ww, int heads, int d, int shift, hipStream_t stream) {
+#define SWF_AC(D) return launch_attn_core_t<D>(batch, nprob, ldq, ldk, ldv, ldo, B, H, W, wh, ww, heads, d, shift, stream)
+    if (d <= 4) SWF_AC(4);
+    if (d <= 8) SWF_AC(8);
+    if (d <= 16) SWF_AC(16);
+    if (d <= 32) SWF_AC(32);
+    if (d <= 64) SWF_AC(64);
+#undef SWF_AC
+    return fail(SWF_ERR_UNSUPPORTED, "head_dim %d > 64", d);
+}
+
+// ------------------------------------------------------------------------------------------
+// patch merge gather / crop / unmerge scatter
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * n - 2 - i; }  // bottom/right only
+
+__global__ __launch_bounds__(256) void merge_gather_kernel(PtrPair pp, int B, int H, int W, int Cin, int mh, int mw,
+                                                           int Hm, int Wm, int Ho, int Wo) {
+    const float* in = pp.in[blockIdx.y];
+    float* out = pp.out[blockIdx.y];
+    const int K = mh * mw * Cin;
+    const int64_t total = (int64_t)B * Ho * Wo * K;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int kc = (int)(e % K);
+        int64_t n = e / K;
+        const int ox = (int)(n % Wo); n /= Wo;
+        const int oy = (int)(n % Ho);
+        const int b = (int)(n / Ho);
+        const int my = reflect_idx(oy, Hm), mx = reflect_idx(ox, Wm);   // window pad of the merged map
+        const int c = kc % Cin, pq = kc / Cin, pw = pq % mw, ph = pq / mw;
+        const int iy = reflect_idx(my * mh + ph, H), ix = reflect_idx(mx * mw + pw, W);  // merge pad of the input
+        out[e] = in[(((int64_t)b * H + iy) * W + ix) * Cin + c];
+    }
+}
+
+int launch_merge_gather(const PtrPair& pp, int nprob, int B, int H, int W, int Cin, int mh, int mw, int Hm, int Wm,
+                        int Ho, int Wo, hipStream_t stream) {
+    const int64_t total = (int64_t)B * Ho * Wo * mh * mw * Cin;
+    dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192), nprob);
+    hipLaunchKernelGGL(merge_gather_kernel, grid, dim3(256), 0, stream, pp, B, H, W, Cin, mh, mw, Hm, Wm, Ho, Wo);
+    return check_launch("merge_gather");
+}
+
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* __restrict__ in, float* __restrict__ out, int B, int H,
+                                                          int W, int C, int ph, int pw) {
+    const int Ho = H + ph, Wo = W + pw;
+    const int64_t total = (int64_t)B * Ho * Wo * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        int64_t n = e / C;
+        const int x = (int)(n % Wo); n /= Wo;
+        const int y = (int)(n % Ho);
+        const int b = (int)(n / Ho);
+        out[e] = in[(((int64_t)b * H + reflect_idx(y, H)) * W + reflect_idx(x, W)) * C + c];
+    }
+}
+
+int launch_reflect_pad(const float* in, float* out, int B, int H, int W, int C, int ph, int pw, hipStream_t stream) {
+    const int64_t total = (int64_t)B * (H + ph) * (W + pw) * C;
+    dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192));
+    hipLaunchKernelGGL(reflect_pad_kernel, grid, dim3(256), 0, stream, in, out, B, H, W, C, ph, pw);
+    return check_launch("reflect_pad");
+}
+
+__global__ __launch_bounds__(256) void crop_kernel(PtrPair pp, int B, int Hp, int Wp, int Hm, int Wm, int C) {
+    const float* in = pp.in[blockIdx.y];
+    float* out = pp.out[blockIdx.y];
+    const int64_t total = (int64_t)B * Hm * Wm * C;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % C);
+        int64_t n = e / C;
+        const int x = (int)(n % Wm); n /= Wm;
+        const int y = (int)(n % Hm);
+        const int b = (int)(n / Hm);
+        out[e] = in[(((int64_t)b * Hp + y) * Wp + x) * C + c];
+    }
+}
+
+int launch_crop(const PtrPair& pp, int nprob, int B, int Hp, int Wp, int Hm, int Wm, int C, hipStream_t stream) {
+    const int64_t total = (int64_t)B * Hm * Wm * C;
+    dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192), nprob);
+    hipLaunchKernelGGL(crop_kernel, grid, dim3(256), 0, stream, pp, B, Hp, Wp, Hm, Wm, C);
+    return check_launch("crop");
+}
+
+__global__ __launch_bounds__(256) void unmerge_scatter_kernel(PtrPair pp, int B, int Hm, int Wm, int Cout, int mh, int mw,
+                                                              int Hout, int Wout) {
+    const float* z = pp.in[blockIdx.y];
+    float* out = pp.out[blockIdx.y];
+    const float* skip = pp.aux[blockIdx.y];
+    const int64_t total = (int64_t)B * Hout * Wout * Cout;
+    const int Kz = mh * mw * Cout;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(e % Cout);
+        int64_t n = e / Cout;
+        const int x = (int)(n % Wout); n /= Wout;
+        const int y = (int)(n % Hout);
+        const int b = (int)(n / Hout);
+        const int my = y / mh, ph = y % mh, mx = x / mw, pw = x % mw;
+        float v = z[(((int64_t)b * Hm + my) * Wm + mx) * Kz + (ph * mw + pw) * Cout + c];
+        v = elu1(v);
+        if (skip) v += skip[e];
+        out[e] = v;
+    }
+}
+
+int launch_unmerge_scatter(const PtrPair& pp, int nprob, int B, int Hm, int Wm, int Cout, int mh, int mw, int Hout,
+                           int Wout, hipStream_t stream) {
+    const int64_t total = (int64_t)B * Hout * Wout * Cout;
+    dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192), nprob);
+    hipLaunchKernelGGL(unmerge_scatter_kernel, grid, dim3(256), 0, stream, pp, B, Hm, Wm, Cout, mh, mw, Hout, Wout);
+    return check_launch("unmerge_scatter");
+}
+
+// ------------------------------------------------------------------------------------------
+// final head (a013:126-152); reflect on all four sides ('same' padding, padding_mode='reflect')
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int reflect2(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(256) void head_conv1_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                         float* __restrict__ tmp, swf_head_params p, int B, int H, int W,
+                                                         int ks) {
+    const int64_t total = (int64_t)B * H * W;
+    const int r = ks / 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(e % W);
+        const int py = (int)((e / W) % H);
+        const int64_t b = e / ((int64_t)W * H);
+        float a0 = p.conv1_b[0], a1 = p.conv1_b[1];
+        for (int ky = 0; ky < ks; ++ky) {
+            const int yy = reflect2(py + ky - r, H);
+            for (int kx = 0; kx < ks; ++kx) {
+                const int xx = reflect2(px + kx - r, W);
+                const int64_t s = (b * H + yy) * W + xx;
+                const float vx = x[s], vy = y[s];
+                // conv1_w [oc][ic][ky][kx], ic 0 = x stream, 1 = y stream (torch.concat([x, y], 1), a013:151)
+                a0 = fmaf(p.conv1_w[((0 * 2 + 0) * ks + ky) * ks + kx], vx, a0);
+                a0 = fmaf(p.conv1_w[((0 * 2 + 1) * ks + ky) * ks + kx], vy, a0);
+                a1 = fmaf(p.conv1_w[((1 * 2 + 0) * ks + ky) * ks + kx], vx, a1);
+                a1 = fmaf(p.conv1_w[((1 * 2 + 1) * ks + ky) * ks + kx], vy, a1);
+            }
+        }
+        a0 = (a0 - p.bn_mean[0]) / sqrtf(p.bn_var[0] + 1e-5f) * p.bn_gamma[0] + p.bn_beta[0];
+        a1 = (a1 - p.bn_mean[1]) / sqrtf(p.bn_var[1] + 1e-5f) * p.bn_gamma[1] + p.bn_beta[1];
+        tmp[e * 2 + 0] = elu1(a0);
+        tmp[e * 2 + 1] = elu1(a1);
+    }
+}
+
+__global__ __launch_bounds__(256) void head_conv2_kernel(const float* __restrict__ tmp, float* __restrict__ out,
+                                                         swf_head_params p, int B, int H, int W, int ks) {
+    const int64_t total = (int64_t)B * H * W;
+    const int r = ks / 2;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int px = (int)(e % W);
+        const int py = (int)((e / W) % H);
+        const int64_t b = e / ((int64_t)W * H);
+        float a = p.conv2_b[0];
+        for (int ky = 0; ky < ks; ++ky) {
+            const int yy = reflect2(py + ky - r, H);
+            for (int kx = 0; kx < ks; ++kx) {
+                const int xx = reflect2(px + kx - r, W);
+                const int64_t s = ((b * H + yy) * W + xx) * 2;
+                a = fmaf(p.conv2_w[(0 * ks + ky) * ks + kx], tmp[s + 0], a);
+                a = fmaf(p.conv2_w[(1 * ks + ky) * ks + kx], tmp[s + 1], a);
+            }
+        }
+        out[e] = a;
+    }
+}
+
+int launch_head_conv1(const float* x, const float* y, float* tmp, const swf_head_params& p, int B, int H, int W, int ks,
+                      hipStream_t stream) {
+    const int64_t total = (int64_t)B * H * W;
+    dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384));
+    hipLaunchKernelGGL(head_conv1_kernel, grid, dim3(256), 0, stream, x, y, tmp, p, B, H, W, ks);
+    return check_launch("head_conv1");
+}
+int launch_head_conv2(const float* tmp, float* out, const swf_head_params& p, int B, int H, int W, int ks,
+                      hipStream_t stream) {
+    const int64_t total = (int64_t)B * H * W;
+    dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384));
+    hipLaunchKernelGGL(head_conv2_kernel, grid, dim3(256), 0, stream, tmp, out, p, B, H, W, ks);
+    return check_launch("head_conv2");
+}
+
+// ------------------------------------------------------------------------------------------
+// NCHW <-> NHWC through a 32x32 LDS tile (both sides coalesced)
+// ------------------------------------------------------------------------------------------
+// in viewed as [B][R][S] -> out [B][S][R]
+__global__ __launch_bounds__(256) void transpose_kernel(const float* __restrict__ in, float* __restrict__ out, int R, int S) {
+    __shared__ float tile[32][33];
+    const int b = blockIdx.z;
+    const int s0 = blockIdx.x * 32, r0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;  // 32 x 8
+    const float* src = in + (int64_t)b * R * S;
+    float* dst = out + (int64_t)b * R * S;
+    for (int i = ty; i < 32; i += 8) {
+        const int r = r0 + i, s = s0 + tx;
+        if (r < R && s < S) tile[i][tx] = src[(int64_t)r * S + s];
+    }
+    __syncthreads();
+    for (int i = ty; i < 32; i += 8) {
+        const int s = s0 + i, r = r0 + tx;
+        if (r < R && s < S) dst[(int64_t)s * R + r] = tile[tx][i];
+    }
+}
+
+static int launch_transpose(const float* in, float* out, int B, int R, int S, hipStream_t stream) {
+    if (B <= 0 || R <= 0 || S <= 0) return fail(SWF_ERR_BAD_SHAPE, "transpose: empty tensor");
+    if (cdiv(R, 32) > 65535 || B > 65535) return fail(SWF_ERR_UNSUPPORTED, "transpose: dims too large");
+    dim3 grid(cdiv(S, 32), cdiv(R, 32), B);
+    hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, stream, in, out, R, S);
+    return check_launch("transpose");
+}
+int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream) {
+    return launch_transpose(in, out, B, C, H * W, stream);
+}
+int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream) {
+    return launch_transpose(in, out, B, H * W, C, stream);
+}
+
+}  // namespace swf

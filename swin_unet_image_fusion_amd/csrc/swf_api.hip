@@ -1,0 +1,716 @@
+// C-ABI entry points of libswinfuse: argument checks, workspace carving and the composition
+// of kernels into the reference's units (WindowAttention, BasicBlock halves, SelfAndCrossBlockPair,
+// PatchMergingAndLinearLayer + MyPadding, final head, MyModel.forward).
+#include <algorithm>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "kernels_generic.h"
+#include "kernels_window.h"
+
+namespace swf {
+
+char* err_buf() {
+    static thread_local char buf[512] = "";
+    return buf;
+}
+int fail(int status, const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(err_buf(), 512, fmt, ap);
+    va_end(ap);
+    return status;
+}
+
+static int check_attn_desc(const swf_attn_desc* d, int B, int H, int W) {
+    if (!d) return fail(SWF_ERR_NULL, "desc is NULL");
+    if (d->channels <= 0 || d->heads <= 0 || d->head_dim <= 0 || d->win_h <= 0 || d->win_w <= 0)
+        return fail(SWF_ERR_BAD_SHAPE, "non-positive attention dims");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(SWF_ERR_BAD_SHAPE, "empty batch or map (%d,%d,%d)", B, H, W);
+    if (H % d->win_h || W % d->win_w)
+        return fail(SWF_ERR_BAD_SHAPE, "map %dx%d is not a multiple of the window %dx%d", H, W, d->win_h, d->win_w);
+    return SWF_OK;
+}
+
+// ---- generic composition -----------------------------------------------------------------
+// Q/K/V projections (three GEMM problems per stream in one launch), attention core, output
+// projection (+ residual).  qsrc/ksrc/vsrc are [N][C] token-major inputs per stream.
+static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn_params* const* prm,
+                             const float* const* qsrc, const float* const* ksrc, const float* const* vsrc,
+                             const float* const* residual, float* const* out, int B, int H, int W, Carver& ws,
+                             hipStream_t stream) {
+    const int64_t N = (int64_t)B * H * W;
+    const int C = d.channels, HD = d.heads * d.head_dim;
+    float* qkv[2][3];
+    float* o[2];
+    for (int s = 0; s < nstream; ++s) {
+        for (int i = 0; i < 3; ++i) qkv[s][i] = ws.floats(N * HD);
+        o[s] = ws.floats(N * HD);
+    }
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "attention workspace too small (need %zu B)", ws.used);
+    GemmBatch gb{};
+    for (int s = 0; s < nstream; ++s) {
+        const swf_linear* lin[3] = {&prm[s]->q, &prm[s]->k, &prm[s]->v};
+        const float* src[3] = {qsrc[s], ksrc[s], vsrc[s]};
+        for (int i = 0; i < 3; ++i) gb.p[s * 3 + i] = GemmProb{src[i], lin[i]->weight, lin[i]->bias, nullptr, qkv[s][i]};
+    }
+    SWF_TRY(launch_gemm_f32(gb, nstream * 3, (int)N, HD, C, C, HD, 0, stream));
+    AttnCoreBatch ab{};
+    for (int s = 0; s < nstream; ++s) ab.p[s] = AttnCoreProb{qkv[s][0], qkv[s][1], qkv[s][2], o[s], prm[s]->bias_table};
+    SWF_TRY(launch_attn_core(ab, nstream, HD, HD, HD, HD, B, H, W, d.win_h, d.win_w, d.heads, d.head_dim, d.shift, stream));
+    GemmBatch pb{};
+    for (int s = 0; s < nstream; ++s)
+        pb.p[s] = GemmProb{o[s], prm[s]->proj.weight, prm[s]->proj.bias, residual ? residual[s] : nullptr, out[s]};
+    SWF_TRY(launch_gemm_f32(pb, nstream, (int)N, C, HD, HD, C, 0, stream));
+    return SWF_OK;
+}
+
+static size_t attention_generic_ws(const swf_attn_desc& d, int nstream, int B, int H, int W) {
+    const int64_t N = (int64_t)B * H * W, HD = (int64_t)d.heads * d.head_dim;
+    size_t total = 0;
+    for (int s = 0; s < nstream; ++s) total += carve_bytes({N * HD, N * HD, N * HD, N * HD});
+    return total;
+}
+
+static int check_stream_params(const swf_block_stream_params* p, const char* which, bool need_attn, bool need_mlp) {
+    if (!p) return fail(SWF_ERR_NULL, "%s params are NULL", which);
+    if (need_attn && (!p->ln1.gamma || !p->ln1.beta || !p->attn.q.weight || !p->attn.k.weight || !p->attn.v.weight ||
+                      !p->attn.proj.weight || !p->attn.bias_table))
+        return fail(SWF_ERR_NULL, "%s: attention half has a NULL weight", which);
+    if (need_mlp && (!p->ln2.gamma || !p->ln2.beta || !p->fc1.weight || !p->fc2.weight))
+        return fail(SWF_ERR_NULL, "%s: MLP half has a NULL weight", which);
+    return SWF_OK;
+}
+
+static int attn_halfblock_generic(const swf_block_desc* desc, const swf_block_stream_params* px,
+                                  const swf_block_stream_params* py, const float* x_in, const float* y_in, float* x_out,
+                                  float* y_out, int B, int H, int W, Carver& ws, hipStream_t stream) {
+    const int nstream = py ? 2 : 1;
+    const int64_t N = (int64_t)B * H * W;
+    const int C = desc->attn.channels;
+    float* xn[2] = {ws.floats(N * C), nstream == 2 ? ws.floats(N * C) : nullptr};
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "attention half-block workspace too small");
+    LnBatch lb{};
+    lb.p[0] = LnProb{x_in, xn[0], px->ln1.gamma, px->ln1.beta};
+    if (nstream == 2) lb.p[1] = LnProb{y_in, xn[1], py->ln1.gamma, py->ln1.beta};
+    SWF_TRY(launch_layernorm(lb, nstream, N, C, 0, stream));
+    const bool cross = desc->cross && nstream == 2;   // single path ignores cross (a002:83)
+    const swf_attn_params* prm[2] = {&px->attn, py ? &py->attn : nullptr};
+    const float* qsrc[2] = {xn[0], xn[1]};
+    const float* kvsrc[2] = {cross ? xn[1] : xn[0], cross ? xn[0] : xn[1]};
+    const float* res[2] = {x_in, y_in};
+    float* out[2] = {x_out, y_out};
+    return attention_generic(desc->attn, nstream, prm, qsrc, kvsrc, kvsrc, res, out, B, H, W, ws, stream);
+}
+
+static int mlp_halfblock_generic(const swf_block_desc* desc, const swf_block_stream_params* px,
+                                 const swf_block_stream_params* py, const float* x_in, const float* y_in, float* x_out,
+                                 float* y_out, int B, int H, int W, Carver& ws, hipStream_t stream) {
+    const int nstream = py ? 2 : 1;
+    const int64_t N = (int64_t)B * H * W;
+    const int C = desc->attn.channels, hid = desc->hidden;
+    float* xn[2] = {ws.floats(N * C), nstream == 2 ? ws.floats(N * C) : nullptr};
+    float* hb[2] = {ws.floats(N * hid), nstream == 2 ? ws.floats(N * hid) : nullptr};
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "MLP half-block workspace too small");
+    LnBatch lb{};
+    lb.p[0] = LnProb{x_in, xn[0], px->ln2.gamma, px->ln2.beta};
+    if (nstream == 2) lb.p[1] = LnProb{y_in, xn[1], py->ln2.gamma, py->ln2.beta};
+    SWF_TRY(launch_layernorm(lb, nstream, N, C, 0, stream));
+    GemmBatch g1{}, g2{};
+    const swf_block_stream_params* pp[2] = {px, py};
+    const float* res[2] = {x_in, y_in};
+    float* out[2] = {x_out, y_out};
+    for (int s = 0; s < nstream; ++s) {
+        g1.p[s] = GemmProb{xn[s], pp[s]->fc1.weight, pp[s]->fc1.bias, nullptr, hb[s]};
+        g2.p[s] = GemmProb{hb[s], pp[s]->fc2.weight, pp[s]->fc2.bias, res[s], out[s]};
+    }
+    SWF_TRY(launch_gemm_f32(g1, nstream, (int)N, hid, C, C, hid, 1, stream));
+    SWF_TRY(launch_gemm_f32(g2, nstream, (int)N, C, hid, hid, C, 0, stream));
+    return SWF_OK;
+}
+
+static size_t block_generic_ws(const swf_block_desc* d, int nstream, int B, int H, int W) {
+    const int64_t N = (int64_t)B * H * W;
+    size_t a = 0, m = 0;
+    for (int s = 0; s < nstream; ++s) a += carve_bytes({N * d->attn.channels});
+    a += attention_generic_ws(d->attn, nstream, B, H, W);
+    for (int s = 0; s < nstream; ++s) m += carve_bytes({N * d->attn.channels}) + carve_bytes({N * d->hidden});
+    return std::max(a, m);
+}
+
+static int check_block(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                       const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
+                       bool attn, bool mlp) {
+    if (!desc) return fail(SWF_ERR_NULL, "desc is NULL");
+    SWF_TRY(check_attn_desc(&desc->attn, B, H, W));
+    if (mlp && desc->hidden <= 0) return fail(SWF_ERR_BAD_SHAPE, "hidden must be positive");
+    SWF_TRY(check_stream_params(px, "x-stream", attn, mlp));
+    if (!x_in || !x_out) return fail(SWF_ERR_NULL, "x tensors are NULL");
+    if (py) {
+        SWF_TRY(check_stream_params(py, "y-stream", attn, mlp));
+        if (!y_in || !y_out) return fail(SWF_ERR_NULL, "y tensors are NULL with dual-path params");
+    }
+    return SWF_OK;
+}
+
+static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_params* px,
+                            const swf_block_stream_params* py, const float* x_in, const float* y_in, float* x_out,
+                            float* y_out, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                            hipStream_t stream) {
+    if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W))
+        return launch_window_block(*desc, *px, *py, x_in, y_in, x_out, y_out, B, H, W, workspace, workspace_bytes, stream);
+    {
+        Carver ws(workspace, workspace_bytes);
+        SWF_TRY(attn_halfblock_generic(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, stream));
+    }
+    Carver ws(workspace, workspace_bytes);
+    return mlp_halfblock_generic(desc, px, py, x_out, y_out, x_out, y_out, B, H, W, ws, stream);
+}
+
+// ---- patch layers -------------------------------------------------------------------------
+static int pad_amount(int len, int mult) { return (mult - len % mult) % mult; }
+
+static int merge_shapes(int H, int W, int mh, int mw, int wh, int ww, int* Hm, int* Wm, int* Ho, int* Wo) {
+    if (H <= 0 || W <= 0 || mh <= 0 || mw <= 0 || wh <= 0 || ww <= 0) return fail(SWF_ERR_BAD_SHAPE, "non-positive size");
+    const int ph = pad_amount(H, mh), pw = pad_amount(W, mw);
+    // F.pad(reflect) requires pad < dim (a006:128 raises RuntimeError otherwise)
+    if (ph >= H || pw >= W) return fail(SWF_ERR_PAD, "reflect pad (%d,%d) >= map (%d,%d) before merging", ph, pw, H, W);
+    *Hm = (H + ph) / mh;
+    *Wm = (W + pw) / mw;
+    const int qh = pad_amount(*Hm, wh), qw = pad_amount(*Wm, ww);
+    if (qh >= *Hm || qw >= *Wm)
+        return fail(SWF_ERR_PAD, "Padding size should be less than the corresponding input dimension: pad (%d,%d) on a %dx%d map",
+                    qh, qw, *Hm, *Wm);
+    *Ho = *Hm + qh;
+    *Wo = *Wm + qw;
+    return SWF_OK;
+}
+
+static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const float* const* in, float* const* out,
+                            int B, int H, int W, int Cin, int Cout, int mh, int mw, int wh, int ww, void* workspace,
+                            size_t workspace_bytes, hipStream_t stream) {
+    int Hm, Wm, Ho, Wo;
+    SWF_TRY(merge_shapes(H, W, mh, mw, wh, ww, &Hm, &Wm, &Ho, &Wo));
+    const int64_t N = (int64_t)B * Ho * Wo;
+    const int K = mh * mw * Cin;
+    Carver ws(workspace, workspace_bytes);
+    float* a[2];
+    float* z[2];
+    for (int s = 0; s < nstream; ++s) { a[s] = ws.floats(N * K); z[s] = ws.floats(N * Cout); }
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "patch-merge workspace too small (need %zu B)", ws.used);
+    PtrPair pp{};
+    GemmBatch gb{};
+    LnBatch lb{};
+    for (int s = 0; s < nstream; ++s) {
+        pp.in[s] = in[s]; pp.out[s] = a[s];
+        gb.p[s] = GemmProb{a[s], p[s]->conv.weight, p[s]->conv.bias, nullptr, z[s]};
+        lb.p[s] = LnProb{z[s], out[s], p[s]->ln.gamma, p[s]->ln.beta};
+    }
+    SWF_TRY(launch_merge_gather(pp, nstream, B, H, W, Cin, mh, mw, Hm, Wm, Ho, Wo, stream));
+    SWF_TRY(launch_gemm_f32(gb, nstream, (int)N, Cout, K, K, Cout, 0, stream));
+    return launch_layernorm(lb, nstream, N, Cout, 1, stream);
+}
+
+static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, const float* const* in,
+                              const float* const* skip, float* const* out, int B, int Hp, int Wp, int Hm, int Wm, int Cin,
+                              int Cout, int mh, int mw, int Hout, int Wout, void* workspace, size_t workspace_bytes,
+                              hipStream_t stream) {
+    if (Hm <= 0 || Wm <= 0 || Hm > Hp || Wm > Wp) return fail(SWF_ERR_BAD_SHAPE, "crop %dx%d of %dx%d", Hm, Wm, Hp, Wp);
+    if (Hout <= 0 || Wout <= 0 || Hout > Hm * mh || Wout > Wm * mw)
+        return fail(SWF_ERR_BAD_SHAPE, "output %dx%d larger than the unmerged map %dx%d", Hout, Wout, Hm * mh, Wm * mw);
+    const int64_t N = (int64_t)B * Hm * Wm;
+    const int Kz = mh * mw * Cout;
+    const bool need_crop = (Hm != Hp) || (Wm != Wp);
+    Carver ws(workspace, workspace_bytes);
+    float* cr[2] = {nullptr, nullptr};
+    float* z[2];
+    float* zn[2];
+    for (int s = 0; s < nstream; ++s) {
+        if (need_crop) cr[s] = ws.floats(N * Cin);
+        z[s] = ws.floats(N * Kz);
+        zn[s] = ws.floats(N * Kz);
+    }
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "patch-unmerge workspace too small (need %zu B)", ws.used);
+    PtrPair cp{}, sp{};
+    GemmBatch gb{};
+    LnBatch lb{};
+    for (int s = 0; s < nstream; ++s) {
+        cp.in[s] = in[s]; cp.out[s] = cr[s];
+        gb.p[s] = GemmProb{need_crop ? cr[s] : in[s], p[s]->conv.weight, p[s]->conv.bias, nullptr, z[s]};
+        lb.p[s] = LnProb{z[s], zn[s], p[s]->ln.gamma, p[s]->ln.beta};
+        sp.in[s] = zn[s]; sp.out[s] = out[s]; sp.aux[s] = skip ? skip[s] : nullptr;
+    }
+    if (need_crop) SWF_TRY(launch_crop(cp, nstream, B, Hp, Wp, Hm, Wm, Cin, stream));
+    SWF_TRY(launch_gemm_f32(gb, nstream, (int)N, Kz, Cin, Cin, Kz, 0, stream));
+    SWF_TRY(launch_layernorm(lb, nstream, N, Kz, 0, stream));
+    return launch_unmerge_scatter(sp, nstream, B, Hm, Wm, Cout, mh, mw, Hout, Wout, stream);
+}
+
+static size_t patch_ws(int nstream, int B, int H, int W, int Cin, int Cout, int mh, int mw, int wh, int ww, int encoder) {
+    size_t total = 0;
+    if (encoder) {
+        int Hm, Wm, Ho, Wo;
+        if (merge_shapes(H, W, mh, mw, wh, ww, &Hm, &Wm, &Ho, &Wo) != SWF_OK) return 0;
+        const int64_t N = (int64_t)B * Ho * Wo;
+        for (int s = 0; s < nstream; ++s) total += carve_bytes({N * mh * mw * Cin, N * Cout});
+    } else {
+        const int64_t N = (int64_t)B * H * W;   // upper bound: uncropped map
+        for (int s = 0; s < nstream; ++s) total += carve_bytes({N * Cin, N * mh * mw * Cout, N * mh * mw * Cout});
+    }
+    return total;
+}
+
+// ---- model layout ---------------------------------------------------------------------------
+struct BlockOff { int64_t ln1g, ln1b, wq, bq, wk, bk, wv, bv, wp, bp, table, ln2g, ln2b, w1, b1, w2, b2; };
+struct PatchOff { int64_t w, b, g, bt; };
+struct ParamEntry { std::string name; int64_t offset, numel; };
+struct ModelLayout {
+    swf_model_desc desc;
+    std::vector<ParamEntry> entries;
+    int64_t total = 0;
+    BlockOff enc_blk[SWF_MAX_LEVELS][4][2], dec_blk[SWF_MAX_LEVELS][4][2];
+    PatchOff enc_patch[SWF_MAX_LEVELS][2], dec_patch[SWF_MAX_LEVELS][2];
+    int64_t h_c1w, h_c1b, h_g, h_b, h_m, h_v, h_c2w, h_c2b;
+
+    int64_t add(const std::string& name, int64_t numel) {
+        const int64_t off = total;
+        entries.push_back({name, off, numel});
+        total += (numel + 3) / 4 * 4;   // keep every tensor 16-byte aligned
+        return off;
+    }
+    void add_blocks(const std::string& prefix, int C, int heads, int hd, int hidden, int wh, int ww, BlockOff (*dst)[2]) {
+        static const char* grp[2] = {"self_att_block.", "cross_att_block."};
+        static const char* blk[2] = {"normal_window_block.", "shifted_window_block."};
+        for (int g = 0; g < 2; ++g)
+            for (int k = 0; k < 2; ++k)
+                for (int s = 0; s < 2; ++s) {
+                    const std::string p = prefix + grp[g] + blk[k];
+                    const std::string st = s == 0 ? "x" : "y";
+                    const std::string nl = s == 0 ? "norm_layer_1." : "norm_layer_2.";
+                    const std::string wa = p + "auto_path_win_att.window_attention_" + st + ".";
+                    const std::string ml = p + "auto_path_mlp.mlp_" + st;
+                    BlockOff& o = dst[g * 2 + k][s];
+                    const int HD = heads * hd;
+                    o.ln1g = add(p + "stage_1." + nl + "weight", C);
+                    o.ln1b = add(p + "stage_1." + nl + "bias", C);
+                    o.wq = add(wa + "q_for_heads.weight", (int64_t)HD * C); o.bq = add(wa + "q_for_heads.bias", HD);
+                    o.wk = add(wa + "k_for_heads.weight", (int64_t)HD * C); o.bk = add(wa + "k_for_heads.bias", HD);
+                    o.wv = add(wa + "v_for_heads.weight", (int64_t)HD * C); o.bv = add(wa + "v_for_heads.bias", HD);
+                    o.wp = add(wa + "linear_projection.weight", (int64_t)C * HD); o.bp = add(wa + "linear_projection.bias", C);
+                    o.table = add(wa + "relative_position_bias_table", (int64_t)(2 * wh - 1) * (2 * ww - 1));
+                    o.ln2g = add(p + "stage_2." + nl + "weight", C);
+                    o.ln2b = add(p + "stage_2." + nl + "bias", C);
+                    o.w1 = add(ml + "_1.weight", (int64_t)hidden * C); o.b1 = add(ml + "_1.bias", hidden);
+                    o.w2 = add(ml + "_2.weight", (int64_t)C * hidden); o.b2 = add(ml + "_2.bias", C);
+                }
+    }
+    void add_patch(const std::string& prefix, int cin, int cout, PatchOff* dst) {
+        for (int s = 0; s < 2; ++s) {
+            const std::string st = s == 0 ? "x" : "y";
+            dst[s].w = add(prefix + "mlp_layer_" + st + ".weight", (int64_t)cin * cout);
+            dst[s].b = add(prefix + "mlp_layer_" + st + ".bias", cout);
+            dst[s].g = add(prefix + "layer_norm_" + st + ".weight", cout);
+            dst[s].bt = add(prefix + "layer_norm_" + st + ".bias", cout);
+        }
+    }
+    void build(const swf_model_desc& d) {
+        desc = d;
+        const int mm = d.merge_h * d.merge_w;
+        for (int s = 0; s < d.levels; ++s) {   // encoder: [pad2, merge(.1), padW, blocks(.3)] (a013:302-311)
+            const std::string e = "encoder_list." + std::to_string(s) + ".";
+            add_patch(e + "1.", d.in_dims[s] * mm, d.out_dims[s], enc_patch[s]);
+            add_blocks(e + "3.", d.out_dims[s], d.heads, d.head_dim[s], d.out_dims[s] * d.mlp_ratio, d.win_h, d.win_w, enc_blk[s]);
+        }
+        for (int j = 0; j < d.levels; ++j) {   // decoder j serves level L-1-j, module order reversed (a013:313-314)
+            const int lvl = d.levels - 1 - j;
+            const std::string e = "decoder_list." + std::to_string(j) + ".";
+            add_blocks(e + "0.", d.out_dims[lvl], d.heads, d.head_dim[lvl], d.in_dims[lvl] * d.mlp_ratio, d.win_h, d.win_w, dec_blk[j]);
+            add_patch(e + "2.", d.out_dims[lvl], d.in_dims[lvl] * mm, dec_patch[j]);
+        }
+        const int k2 = d.head_ksize * d.head_ksize;
+        h_c1w = add("final_layer.0.weight", 2 * 2 * k2); h_c1b = add("final_layer.0.bias", 2);
+        h_g = add("final_layer.1.weight", 2); h_b = add("final_layer.1.bias", 2);
+        h_m = add("final_layer.1.running_mean", 2); h_v = add("final_layer.1.running_var", 2);
+        h_c2w = add("final_layer.3.weight", 2 * k2); h_c2b = add("final_layer.3.bias", 1);
+    }
+};
+
+static int check_model_desc(const swf_model_desc* d) {
+    if (!d) return fail(SWF_ERR_NULL, "model desc is NULL");
+    if (d->levels <= 0 || d->levels > SWF_MAX_LEVELS) return fail(SWF_ERR_BAD_SHAPE, "levels %d outside 1..%d", d->levels, SWF_MAX_LEVELS);
+    if (d->heads <= 0 || d->mlp_ratio <= 0 || d->win_h <= 0 || d->win_w <= 0 || d->merge_h <= 0 || d->merge_w <= 0)
+        return fail(SWF_ERR_BAD_SHAPE, "non-positive model dims");
+    if (d->head_ksize <= 0 || d->head_ksize % 2 == 0) return fail(SWF_ERR_UNSUPPORTED, "final conv kernel must be odd");
+    for (int s = 0; s < d->levels; ++s) {
+        if (d->in_dims[s] <= 0 || d->out_dims[s] <= 0 || d->head_dim[s] <= 0) return fail(SWF_ERR_BAD_SHAPE, "non-positive dims at level %d", s);
+        if (s > 0 && d->in_dims[s] != d->out_dims[s - 1])
+            return fail(SWF_ERR_BAD_SHAPE, "in_dims[%d]=%d != out_dims[%d]=%d", s, d->in_dims[s], s - 1, d->out_dims[s - 1]);
+    }
+    if (d->in_dims[0] != 1) return fail(SWF_ERR_UNSUPPORTED, "in_dims[0] must be 1 (single-channel IR / Y inputs, final head takes 2 channels)");
+    return SWF_OK;
+}
+
+// Layouts are cached per descriptor; the key is a canonical copy (unused levels and struct padding
+// zeroed) so that callers need not zero-initialise the struct.
+static swf_model_desc canonical_desc(const swf_model_desc* d) {
+    swf_model_desc c;
+    std::memset(&c, 0, sizeof(c));
+    c.levels = d->levels;
+    for (int s = 0; s < d->levels; ++s) { c.in_dims[s] = d->in_dims[s]; c.out_dims[s] = d->out_dims[s]; c.head_dim[s] = d->head_dim[s]; }
+    c.heads = d->heads; c.mlp_ratio = d->mlp_ratio;
+    c.win_h = d->win_h; c.win_w = d->win_w; c.merge_h = d->merge_h; c.merge_w = d->merge_w;
+    c.head_ksize = d->head_ksize;
+    c.precision = 0;   // the parameter layout does not depend on the arithmetic mode
+    return c;
+}
+
+static const ModelLayout* get_layout(const swf_model_desc* d_in) {
+    const swf_model_desc canon = canonical_desc(d_in);
+    const swf_model_desc* d = &canon;
+    static std::mutex mu;
+    static std::vector<ModelLayout*> cache;
+    std::lock_guard<std::mutex> lock(mu);
+    for (ModelLayout* l : cache)
+        if (std::memcmp(&l->desc, d, sizeof(*d)) == 0) return l;
+    ModelLayout* l = new ModelLayout();
+    l->build(*d);
+    cache.push_back(l);
+    return l;
+}
+
+static swf_block_stream_params make_stream_params(const float* a, const BlockOff& o) {
+    swf_block_stream_params p;
+    p.ln1 = {a + o.ln1g, a + o.ln1b};
+    p.attn.q = {a + o.wq, a + o.bq}; p.attn.k = {a + o.wk, a + o.bk}; p.attn.v = {a + o.wv, a + o.bv};
+    p.attn.proj = {a + o.wp, a + o.bp}; p.attn.bias_table = a + o.table;
+    p.ln2 = {a + o.ln2g, a + o.ln2b};
+    p.fc1 = {a + o.w1, a + o.b1}; p.fc2 = {a + o.w2, a + o.b2};
+    return p;
+}
+
+struct LevelShape { int Hin, Win, Hm, Wm, Ho, Wo; };
+
+static int model_shapes(const swf_model_desc* d, int H, int W, LevelShape* ls) {
+    int h = H, w = W;
+    for (int s = 0; s < d->levels; ++s) {
+        ls[s].Hin = h; ls[s].Win = w;
+        SWF_TRY(merge_shapes(h, w, d->merge_h, d->merge_w, d->win_h, d->win_w, &ls[s].Hm, &ls[s].Wm, &ls[s].Ho, &ls[s].Wo));
+        h = ls[s].Ho; w = ls[s].Wo;
+    }
+    if (d->head_ksize / 2 >= H || d->head_ksize / 2 >= W) return fail(SWF_ERR_PAD, "final conv reflect pad >= image");
+    return SWF_OK;
+}
+
+static swf_block_desc level_block_desc(const swf_model_desc* d, int lvl, bool encoder) {
+    swf_block_desc b;
+    b.attn.channels = d->out_dims[lvl];
+    b.attn.heads = d->heads;
+    b.attn.head_dim = d->head_dim[lvl];
+    b.attn.win_h = d->win_h; b.attn.win_w = d->win_w;
+    b.attn.shift = 0;
+    b.hidden = (encoder ? d->out_dims[lvl] : d->in_dims[lvl]) * d->mlp_ratio;
+    b.cross = 0;
+    b.precision = d->precision;
+    return b;
+}
+
+static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                            const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
+                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+    const float* xi = x_in;
+    const float* yi = y_in;
+    for (int i = 0; i < 4; ++i) {
+        swf_block_desc d = *desc;
+        d.cross = i >= 2;          // self pair first, then cross pair (a012:72-73)
+        d.attn.shift = i & 1;      // normal window, then shifted window (a009:102-105)
+        SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream));
+        xi = x_out; yi = y_out;
+    }
+    return SWF_OK;
+}
+
+}  // namespace swf
+
+using namespace swf;
+
+extern "C" {
+
+int swf_version(void) { return SWF_VERSION_MAJOR * 1000 + SWF_VERSION_MINOR; }
+const char* swf_last_error_string(void) { return err_buf(); }
+const char* swf_status_string(int status) {
+    switch (status) {
+        case SWF_OK: return "ok";
+        case SWF_ERR_NULL: return "null pointer";
+        case SWF_ERR_BAD_SHAPE: return "bad shape";
+        case SWF_ERR_PAD: return "reflect padding >= dimension";
+        case SWF_ERR_UNSUPPORTED: return "unsupported configuration";
+        case SWF_ERR_WORKSPACE: return "workspace too small";
+        case SWF_ERR_HIP: return "HIP error";
+        default: return "unknown status";
+    }
+}
+
+size_t swf_window_attention_workspace_bytes(const swf_attn_desc* desc, int32_t B, int32_t H, int32_t W) {
+    if (!desc || B <= 0 || H <= 0 || W <= 0) return 0;
+    return attention_generic_ws(*desc, 1, B, H, W);
+}
+
+int swf_window_attention_fwd(const swf_attn_desc* desc, const swf_attn_params* p, const float* q, const float* k,
+                             const float* v, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
+                             void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    SWF_TRY(check_attn_desc(desc, B, H, W));
+    if (!p || !q || !k || !v || !out) return fail(SWF_ERR_NULL, "window_attention: NULL tensor or params");
+    if (!p->q.weight || !p->k.weight || !p->v.weight || !p->proj.weight || !p->bias_table)
+        return fail(SWF_ERR_NULL, "window_attention: NULL weight");
+    Carver ws(workspace, workspace_bytes);
+    const swf_attn_params* prm[2] = {p, nullptr};
+    const float* qs[2] = {q, nullptr};
+    const float* ks[2] = {k, nullptr};
+    const float* vs[2] = {v, nullptr};
+    const float* rs[2] = {residual, nullptr};
+    float* os[2] = {out, nullptr};
+    return attention_generic(*desc, 1, prm, qs, ks, vs, residual ? rs : nullptr, os, B, H, W, ws, as_stream(stream));
+}
+
+size_t swf_basic_block_workspace_bytes(const swf_block_desc* desc, int32_t B, int32_t H, int32_t W) {
+    if (!desc || B <= 0 || H <= 0 || W <= 0) return 0;
+    return std::max(block_generic_ws(desc, 2, B, H, W), window_block_workspace_bytes(*desc, B, H, W));
+}
+
+int swf_attn_halfblock_fwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                           const float* x_in, const float* y_in, float* x_out, float* y_out, int32_t B, int32_t H, int32_t W,
+                           void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    SWF_TRY(check_block(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, true, false));
+    Carver ws(workspace, workspace_bytes);
+    return attn_halfblock_generic(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, as_stream(stream));
+}
+
+int swf_mlp_halfblock_fwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                          const float* x_in, const float* y_in, float* x_out, float* y_out, int32_t B, int32_t H, int32_t W,
+                          void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    SWF_TRY(check_block(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, false, true));
+    Carver ws(workspace, workspace_bytes);
+    return mlp_halfblock_generic(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, as_stream(stream));
+}
+
+int swf_basic_block_fwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                        const float* x_in, const float* y_in, float* x_out, float* y_out, int32_t B, int32_t H, int32_t W,
+                        void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    SWF_TRY(check_block(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, true, true));
+    return basic_block_impl(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, workspace, workspace_bytes, as_stream(stream));
+}
+
+int swf_block_pair4_fwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                        const float* x_in, const float* y_in, float* x_out, float* y_out, int32_t B, int32_t H, int32_t W,
+                        void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    if (!px) return fail(SWF_ERR_NULL, "block params are NULL");
+    for (int i = 0; i < 4; ++i)
+        SWF_TRY(check_block(desc, &px[i], py ? &py[i] : nullptr, x_in, y_in, x_out, y_out, B, H, W, true, true));
+    return block_pair4_impl(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, workspace, workspace_bytes, as_stream(stream));
+}
+
+int swf_merge_out_shape(int32_t H, int32_t W, int32_t merge_h, int32_t merge_w, int32_t win_h, int32_t win_w, int32_t* Hm,
+                        int32_t* Wm, int32_t* Ho, int32_t* Wo) {
+    if (!Hm || !Wm || !Ho || !Wo) return fail(SWF_ERR_NULL, "output pointer is NULL");
+    return merge_shapes(H, W, merge_h, merge_w, win_h, win_w, Hm, Wm, Ho, Wo);
+}
+
+size_t swf_patch_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t merge_h,
+                                 int32_t merge_w, int32_t win_h, int32_t win_w, int32_t encoder) {
+    if (B <= 0 || H <= 0 || W <= 0) return 0;
+    return patch_ws(1, B, H, W, Cin, Cout, merge_h, merge_w, win_h, win_w, encoder);
+}
+
+int swf_patch_merge_fwd(const swf_patch_params* p, const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t Cin,
+                        int32_t Cout, int32_t merge_h, int32_t merge_w, int32_t win_h, int32_t win_w, void* workspace,
+                        size_t workspace_bytes, swf_stream_t stream) {
+    if (!p || !in || !out || !p->conv.weight || !p->ln.gamma || !p->ln.beta) return fail(SWF_ERR_NULL, "patch_merge: NULL argument");
+    if (B <= 0 || Cin <= 0 || Cout <= 0) return fail(SWF_ERR_BAD_SHAPE, "patch_merge: non-positive dims");
+    const swf_patch_params* pp[2] = {p, nullptr};
+    const float* ins[2] = {in, nullptr};
+    float* outs[2] = {out, nullptr};
+    return patch_merge_impl(pp, 1, ins, outs, B, H, W, Cin, Cout, merge_h, merge_w, win_h, win_w, workspace, workspace_bytes,
+                            as_stream(stream));
+}
+
+int swf_patch_unmerge_fwd(const swf_patch_params* p, const float* in, const float* skip, float* out, int32_t B, int32_t Hp,
+                          int32_t Wp, int32_t Hm, int32_t Wm, int32_t Cin, int32_t Cout, int32_t merge_h, int32_t merge_w,
+                          int32_t Hout, int32_t Wout, void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    if (!p || !in || !out || !p->conv.weight || !p->ln.gamma || !p->ln.beta) return fail(SWF_ERR_NULL, "patch_unmerge: NULL argument");
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || merge_h <= 0 || merge_w <= 0) return fail(SWF_ERR_BAD_SHAPE, "patch_unmerge: non-positive dims");
+    const swf_patch_params* pp[2] = {p, nullptr};
+    const float* ins[2] = {in, nullptr};
+    const float* sk[2] = {skip, nullptr};
+    float* outs[2] = {out, nullptr};
+    return patch_unmerge_impl(pp, 1, ins, skip ? sk : nullptr, outs, B, Hp, Wp, Hm, Wm, Cin, Cout, merge_h, merge_w, Hout, Wout,
+                              workspace, workspace_bytes, as_stream(stream));
+}
+
+int swf_final_head_fwd(const swf_head_params* p, const float* x, const float* y, float* out, int32_t B, int32_t H, int32_t W,
+                       int32_t ksize, void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    if (!p || !x || !y || !out) return fail(SWF_ERR_NULL, "final_head: NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(SWF_ERR_BAD_SHAPE, "final_head: empty tensor");
+    if (ksize <= 0 || ksize % 2 == 0) return fail(SWF_ERR_UNSUPPORTED, "final_head: even kernel size %d", ksize);
+    if (ksize / 2 >= H || ksize / 2 >= W) return fail(SWF_ERR_PAD, "final_head: reflect pad %d >= map %dx%d", ksize / 2, H, W);
+    Carver ws(workspace, workspace_bytes);
+    float* tmp = ws.floats((int64_t)B * H * W * 2);
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "final_head workspace too small (need %zu B)", ws.used);
+    SWF_TRY(launch_head_conv1(x, y, tmp, *p, B, H, W, ksize, as_stream(stream)));
+    return launch_head_conv2(tmp, out, *p, B, H, W, ksize, as_stream(stream));
+}
+
+int swf_linear_fwd(const swf_linear* lin, const float* in, const float* residual, float* out, int64_t tokens, int32_t n_in,
+                   int32_t n_out, int32_t act, swf_stream_t stream) {
+    if (!lin || !lin->weight || !in || !out) return fail(SWF_ERR_NULL, "linear: NULL argument");
+    if (tokens <= 0 || tokens > INT32_MAX || n_in <= 0 || n_out <= 0) return fail(SWF_ERR_BAD_SHAPE, "linear: bad sizes");
+    if (act != 0 && act != 1) return fail(SWF_ERR_UNSUPPORTED, "linear: activation %d", act);
+    GemmBatch gb{};
+    gb.p[0] = GemmProb{in, lin->weight, lin->bias, residual, out};
+    return launch_gemm_f32(gb, 1, (int)tokens, n_out, n_in, n_in, n_out, act, as_stream(stream));
+}
+
+int swf_layernorm_fwd(const swf_norm* ln, const float* in, float* out, int64_t tokens, int32_t C, int32_t elu, swf_stream_t stream) {
+    if (!ln || !ln->gamma || !ln->beta || !in || !out) return fail(SWF_ERR_NULL, "layernorm: NULL argument");
+    if (tokens <= 0 || C <= 0) return fail(SWF_ERR_BAD_SHAPE, "layernorm: bad sizes");
+    LnBatch lb{};
+    lb.p[0] = LnProb{in, out, ln->gamma, ln->beta};
+    return launch_layernorm(lb, 1, tokens, C, elu ? 1 : 0, as_stream(stream));
+}
+
+int swf_reflect_pad_fwd(const float* in, float* out, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad_h, int32_t pad_w,
+                        swf_stream_t stream) {
+    if (!in || !out) return fail(SWF_ERR_NULL, "reflect_pad: NULL tensor");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || pad_h < 0 || pad_w < 0) return fail(SWF_ERR_BAD_SHAPE, "reflect_pad: bad sizes");
+    if (pad_h >= H || pad_w >= W)
+        return fail(SWF_ERR_PAD, "Padding size should be less than the corresponding input dimension: pad (%d,%d) on a %dx%d map", pad_h, pad_w, H, W);
+    return launch_reflect_pad(in, out, B, H, W, C, pad_h, pad_w, as_stream(stream));
+}
+
+int swf_crop_fwd(const float* in, float* out, int32_t B, int32_t Hp, int32_t Wp, int32_t H, int32_t W, int32_t C, swf_stream_t stream) {
+    if (!in || !out) return fail(SWF_ERR_NULL, "crop: NULL tensor");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || H > Hp || W > Wp) return fail(SWF_ERR_BAD_SHAPE, "crop: bad sizes");
+    PtrPair pp{};
+    pp.in[0] = in; pp.out[0] = out;
+    return launch_crop(pp, 1, B, Hp, Wp, H, W, C, as_stream(stream));
+}
+
+int swf_nchw_to_nhwc(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W, swf_stream_t stream) {
+    if (!in || !out) return fail(SWF_ERR_NULL, "layout: NULL tensor");
+    return launch_nchw_to_nhwc(in, out, B, C, H, W, as_stream(stream));
+}
+int swf_nhwc_to_nchw(const float* in, float* out, int32_t B, int32_t C, int32_t H, int32_t W, swf_stream_t stream) {
+    if (!in || !out) return fail(SWF_ERR_NULL, "layout: NULL tensor");
+    return launch_nhwc_to_nchw(in, out, B, C, H, W, as_stream(stream));
+}
+
+// ---- model ------------------------------------------------------------------------------------
+int32_t swf_model_param_count(const swf_model_desc* desc) {
+    if (check_model_desc(desc) != SWF_OK) return -1;
+    return (int32_t)get_layout(desc)->entries.size();
+}
+int64_t swf_model_arena_elems(const swf_model_desc* desc) {
+    if (check_model_desc(desc) != SWF_OK) return -1;
+    return get_layout(desc)->total;
+}
+int swf_model_param_info(const swf_model_desc* desc, int32_t index, char* name_buf, size_t name_buf_len, int64_t* offset_elems,
+                         int64_t* numel) {
+    SWF_TRY(check_model_desc(desc));
+    const ModelLayout* l = get_layout(desc);
+    if (index < 0 || index >= (int32_t)l->entries.size()) return fail(SWF_ERR_BAD_SHAPE, "param index %d out of range", index);
+    const ParamEntry& e = l->entries[index];
+    if (name_buf && name_buf_len) {
+        if (e.name.size() + 1 > name_buf_len) return fail(SWF_ERR_WORKSPACE, "name buffer too small (%zu needed)", e.name.size() + 1);
+        std::memcpy(name_buf, e.name.c_str(), e.name.size() + 1);
+    }
+    if (offset_elems) *offset_elems = e.offset;
+    if (numel) *numel = e.numel;
+    return SWF_OK;
+}
+
+// workspace layout: per level two activation maps (x, y), two full-resolution decoder outputs,
+// then one scratch region shared by every unit.
+static size_t model_scratch_bytes(const swf_model_desc* d, int B, const LevelShape* ls) {
+    size_t scratch = 0;
+    for (int s = 0; s < d->levels; ++s) {
+        swf_block_desc be = level_block_desc(d, s, true), bd = level_block_desc(d, s, false);
+        scratch = std::max(scratch, std::max(block_generic_ws(&be, 2, B, ls[s].Ho, ls[s].Wo), block_generic_ws(&bd, 2, B, ls[s].Ho, ls[s].Wo)));
+        scratch = std::max(scratch, std::max(window_block_workspace_bytes(be, B, ls[s].Ho, ls[s].Wo), window_block_workspace_bytes(bd, B, ls[s].Ho, ls[s].Wo)));
+        scratch = std::max(scratch, patch_ws(2, B, ls[s].Hin, ls[s].Win, d->in_dims[s], d->out_dims[s], d->merge_h, d->merge_w, d->win_h, d->win_w, 1));
+        scratch = std::max(scratch, patch_ws(2, B, ls[s].Ho, ls[s].Wo, d->out_dims[s], d->in_dims[s], d->merge_h, d->merge_w, d->win_h, d->win_w, 0));
+    }
+    scratch = std::max(scratch, carve_bytes({(int64_t)B * ls[0].Hin * ls[0].Win * 2}));
+    return scratch;
+}
+
+size_t swf_model_workspace_bytes(const swf_model_desc* desc, int32_t B, int32_t H, int32_t W) {
+    if (check_model_desc(desc) != SWF_OK || B <= 0) return 0;
+    LevelShape ls[SWF_MAX_LEVELS];
+    if (model_shapes(desc, H, W, ls) != SWF_OK) return 0;
+    size_t total = 0;
+    for (int s = 0; s < desc->levels; ++s) total += 2 * carve_bytes({(int64_t)B * ls[s].Ho * ls[s].Wo * desc->out_dims[s]});
+    total += 2 * carve_bytes({(int64_t)B * H * W * desc->in_dims[0]});
+    return total + model_scratch_bytes(desc, B, ls) + 256;
+}
+
+int swf_model_forward(const swf_model_desc* desc, const float* arena, const float* ir, const float* vis, float* out,
+                      int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream_) {
+    SWF_TRY(check_model_desc(desc));
+    if (!arena || !ir || !vis || !out) return fail(SWF_ERR_NULL, "model_forward: NULL tensor");
+    if (B <= 0) return fail(SWF_ERR_BAD_SHAPE, "model_forward: empty batch");
+    LevelShape ls[SWF_MAX_LEVELS];
+    SWF_TRY(model_shapes(desc, H, W, ls));
+    const ModelLayout* L = get_layout(desc);
+    hipStream_t stream = as_stream(stream_);
+    const int n = desc->levels;
+    Carver ws(workspace, workspace_bytes);
+    float* act[SWF_MAX_LEVELS][2];
+    for (int s = 0; s < n; ++s)
+        for (int t = 0; t < 2; ++t) act[s][t] = ws.floats((int64_t)B * ls[s].Ho * ls[s].Wo * desc->out_dims[s]);
+    float* full[2] = {ws.floats((int64_t)B * H * W * desc->in_dims[0]), ws.floats((int64_t)B * H * W * desc->in_dims[0])};
+    const size_t scratch_bytes = model_scratch_bytes(desc, B, ls);
+    size_t scratch_off = align_up(ws.used, 256);
+    if (!workspace || scratch_off + scratch_bytes > workspace_bytes)
+        return fail(SWF_ERR_WORKSPACE, "model workspace too small: have %zu B, need %zu B", workspace_bytes, scratch_off + scratch_bytes);
+    void* scratch = static_cast<char*>(workspace) + scratch_off;
+
+    auto patch_params = [&](const PatchOff& o) { return swf_patch_params{{arena + o.w, arena + o.b}, {arena + o.g, arena + o.bt}}; };
+
+    // encoder (a013:215-220)
+    const float* cur[2] = {ir, vis};
+    for (int s = 0; s < n; ++s) {
+        swf_patch_params pm[2] = {patch_params(L->enc_patch[s][0]), patch_params(L->enc_patch[s][1])};
+        const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
+        SWF_TRY(patch_merge_impl(pmp, 2, cur, act[s], B, ls[s].Hin, ls[s].Win, desc->in_dims[s], desc->out_dims[s], desc->merge_h,
+                                 desc->merge_w, desc->win_h, desc->win_w, scratch, scratch_bytes, stream));
+        swf_block_stream_params px[4], py[4];
+        for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->enc_blk[s][i][0]); py[i] = make_stream_params(arena, L->enc_blk[s][i][1]); }
+        swf_block_desc bd = level_block_desc(desc, s, true);
+        SWF_TRY(block_pair4_impl(&bd, px, py, act[s][0], act[s][1], act[s][0], act[s][1], B, ls[s].Ho, ls[s].Wo, scratch, scratch_bytes, stream));
+        cur[0] = act[s][0]; cur[1] = act[s][1];
+    }
+    // decoder (a013:221-227): the skip add of stage j+1 is folded into stage j's unmerge epilogue,
+    // written in place over the encoder activation of the level below.
+    for (int j = 0; j < n; ++j) {
+        const int lvl = n - 1 - j;
+        swf_block_stream_params px[4], py[4];
+        for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->dec_blk[j][i][0]); py[i] = make_stream_params(arena, L->dec_blk[j][i][1]); }
+        swf_block_desc bd = level_block_desc(desc, lvl, false);
+        SWF_TRY(block_pair4_impl(&bd, px, py, act[lvl][0], act[lvl][1], act[lvl][0], act[lvl][1], B, ls[lvl].Ho, ls[lvl].Wo, scratch, scratch_bytes, stream));
+        swf_patch_params pm[2] = {patch_params(L->dec_patch[j][0]), patch_params(L->dec_patch[j][1])};
+        const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
+        const float* ins[2] = {act[lvl][0], act[lvl][1]};
+        const float* skip[2] = {lvl > 0 ? act[lvl - 1][0] : nullptr, lvl > 0 ? act[lvl - 1][1] : nullptr};
+        float* outs[2] = {lvl > 0 ? act[lvl - 1][0] : full[0], lvl > 0 ? act[lvl - 1][1] : full[1]};
+        SWF_TRY(patch_unmerge_impl(pmp, 2, ins, lvl > 0 ? skip : nullptr, outs, B, ls[lvl].Ho, ls[lvl].Wo, ls[lvl].Hm, ls[lvl].Wm,
+                                   desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, ls[lvl].Hin, ls[lvl].Win,
+                                   scratch, scratch_bytes, stream));
+    }
+    swf_head_params hp{arena + L->h_c1w, arena + L->h_c1b, arena + L->h_g, arena + L->h_b, arena + L->h_m, arena + L->h_v,
+                       arena + L->h_c2w, arena + L->h_c2b};
+    float* tmp = static_cast<float*>(scratch);
+    SWF_TRY(launch_head_conv1(full[0], full[1], tmp, hp, B, H, W, desc->head_ksize, stream));
+    return launch_head_conv2(tmp, out, hp, B, H, W, desc->head_ksize, stream);
+}
+
+}  // extern "C"

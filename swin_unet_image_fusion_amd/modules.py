@@ -1,0 +1,733 @@
+"""Host-side mirror of the reference's module API, backed by libswinfuse (HIP, gfx950).
+
+Same class names, constructor signatures, `forward` / `forward_` signatures and state_dict
+keys as the reference (a001..a013), so `load_state_dict` of a reference checkpoint is strict-
+compatible and callers (a016:150, a017:72) can switch by changing an import.  The classes own
+ordinary `nn.Parameter`s (inside nn.Linear / nn.Conv2d / nn.LayerNorm / nn.BatchNorm2d
+containers, which are used purely as named parameter holders); every `forward` marshals raw
+device pointers into the C-ABI.  No arithmetic of the hot path runs in PyTorch, and there is
+no CPU fallback: without the built library, or on a CPU tensor, forward raises.
+
+Only the eval()/no_grad forward exists (SURVEY.md §8b "Mode").
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from collections import deque
+from typing import List, Optional, Tuple
+
+import torch
+from torch import Tensor, nn
+
+from . import _lib as L
+
+__all__ = ["WindowAttention", "AutoPathWinAtt", "AutoPathMLP", "AddAndLayerNormWithOtherModule", "BasicBlock",
+           "NormalAndShiftWinsBlockPair", "SelfAndCrossBlockPair", "PatchMergingAndLinearLayer", "MyPadding",
+           "StateRecorder", "MyModel", "get_encoder_or_decoder_block"]
+
+
+# ----------------------------------------------------------------------------------------------
+# plumbing: pointers, streams, workspaces, layout changes
+# ----------------------------------------------------------------------------------------------
+def _ptr(t: Optional[Tensor]) -> Optional[int]:
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise RuntimeError("libswinfuse needs contiguous fp32 tensors on the GPU "
+                           f"(got dtype={t.dtype}, device={t.device}, contiguous={t.is_contiguous()})")
+    return t.data_ptr()
+
+
+def _stream(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+_WS = {}
+
+
+def _workspace(nbytes: int, device) -> Tuple[Optional[int], int]:
+    """Grow-only scratch buffer per (device, stream); the library only borrows it for one call."""
+    if nbytes <= 0:
+        return None, 0
+    key = (torch.device(device).index, _stream(device))
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(int(nbytes * 1.25) + 256, dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf.data_ptr(), buf.numel()
+
+
+def _check_forward_only(module: nn.Module, *tensors: Optional[Tensor]) -> None:
+    if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
+        raise RuntimeError("libswinfuse provides the forward pass only; call it under torch.no_grad() "
+                           "with inputs that do not require grad")
+    for t in tensors:
+        if t is not None and (t.dim() != 4):
+            raise ValueError(f"expected a 4-D (batch, channels, height, width) tensor, got shape {tuple(t.shape)}")
+
+
+def _to_nhwc(t: Tensor) -> Tensor:
+    b, c, h, w = t.shape
+    t = t.contiguous()
+    if c == 1:
+        return t.view(b, h, w, 1)
+    out = torch.empty((b, h, w, c), dtype=torch.float32, device=t.device)
+    L.check(L.lib().swf_nchw_to_nhwc(_ptr(t), _ptr(out), b, c, h, w, _stream(t.device)))
+    return out
+
+
+def _to_nchw(t: Tensor) -> Tensor:
+    b, h, w, c = t.shape
+    if c == 1:
+        return t.view(b, 1, h, w)
+    out = torch.empty((b, c, h, w), dtype=torch.float32, device=t.device)
+    L.check(L.lib().swf_nhwc_to_nchw(_ptr(t), _ptr(out), b, c, h, w, _stream(t.device)))
+    return out
+
+
+def _lin(mod: nn.Module) -> L.Linear:
+    return L.Linear(_ptr(mod.weight), _ptr(mod.bias) if mod.bias is not None else None)
+
+
+def _norm(mod: nn.LayerNorm) -> L.Norm:
+    return L.Norm(_ptr(mod.weight), _ptr(mod.bias))
+
+
+def _require_elu(act: nn.Module) -> None:
+    if not isinstance(act, nn.ELU) or float(act.alpha) != 1.0:
+        raise NotImplementedError("the HIP kernels implement the reference's configured activation, "
+                                  f"nn.ELU(alpha=1) (A000_CONFIG.py:64); got {act!r}")
+
+
+def _precision_code(p) -> int:
+    if p in (L.PREC_FP32, "fp32"):
+        return L.PREC_FP32
+    if p in (L.PREC_FAST, "fast"):
+        return L.PREC_FAST
+    raise ValueError(f"precision must be 'fast' or 'fp32', got {p!r}")
+
+
+class StateRecorder:
+    """LIFO used for pad sizes, shapes and U-Net skips (reference a010_StateRecorder.py:1-18)."""
+
+    def __init__(self):
+        self.record_stack = []
+
+    def record(self, new_item):
+        self.record_stack.append(new_item)
+
+    def read(self):
+        return self.record_stack.pop()
+
+    def delete_all(self):
+        self.record_stack.clear()
+
+    def peek(self):
+        return self.record_stack[-1] if self.record_stack else None
+
+
+class _FwdAlias:
+    def forward_(self, *a, **kw):  # every reference module has this alias (a001:476, a012:80, a013:232)
+        return self(*a, **kw)
+
+
+# ----------------------------------------------------------------------------------------------
+# a001 WindowAttention
+# ----------------------------------------------------------------------------------------------
+class WindowAttention(_FwdAlias, nn.Module):
+    """Drop-in for a001_WindowAttention.WindowAttention (ctor a001:9-20, forward a001:448-474)."""
+
+    def __init__(self, in_out_dims: int, num_heads: int, dims_per_head: int, window_size: tuple,
+                 use_cyclic_shift: bool, use_cross_attention: bool, use_qkv_bias: bool,
+                 attention_drop_ratio: float, linear_after_att_drop_ratio: float):
+        super().__init__()
+        self.in_out_dims, self.num_heads, self.dims_per_head = in_out_dims, num_heads, dims_per_head
+        self.window_size = tuple(window_size)
+        self.use_cyclic_shift, self.use_cross_attention, self.use_qkv_bias = use_cyclic_shift, use_cross_attention, use_qkv_bias
+        self.attention_drop_ratio, self.linear_after_att_drop_ratio = attention_drop_ratio, linear_after_att_drop_ratio
+        self.qk_scale = dims_per_head ** -0.5
+        self.feature_shape_hw: tuple = tuple()
+        hd = num_heads * dims_per_head
+        self.q_for_heads = nn.Linear(in_out_dims, hd, bias=use_qkv_bias)
+        self.k_for_heads = nn.Linear(in_out_dims, hd, bias=use_qkv_bias)
+        self.v_for_heads = nn.Linear(in_out_dims, hd, bias=use_qkv_bias)
+        self.linear_projection = nn.Linear(hd, in_out_dims)
+        self.relative_position_bias_table = nn.Parameter(
+            torch.randn(2 * self.window_size[0] - 1, 2 * self.window_size[1] - 1))
+
+    def _desc(self) -> L.AttnDesc:
+        return L.AttnDesc(self.in_out_dims, self.num_heads, self.dims_per_head, self.window_size[0],
+                          self.window_size[1], int(bool(self.use_cyclic_shift)))
+
+    def _params(self) -> L.AttnParams:
+        return L.AttnParams(_lin(self.q_for_heads), _lin(self.k_for_heads), _lin(self.v_for_heads),
+                            _lin(self.linear_projection), _ptr(self.relative_position_bias_table))
+
+    def _check_dropout(self):
+        if self.training and (self.attention_drop_ratio or self.linear_after_att_drop_ratio):
+            raise NotImplementedError("dropout > 0 in training mode is outside the forward-only HIP path")
+
+    def forward(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+        _check_forward_only(self, q, k, v)
+        self._check_dropout()
+        if q.shape != k.shape or q.shape != v.shape:
+            raise ValueError(f"q, k, v must share one shape, got {tuple(q.shape)}, {tuple(k.shape)}, {tuple(v.shape)}")
+        b, c, h, w = q.shape
+        if c != self.in_out_dims:
+            raise RuntimeError(f"expected {self.in_out_dims} channels, got {c}")
+        self.feature_shape_hw = (h, w)
+        qn = _to_nhwc(q)
+        kn = qn if k is q else _to_nhwc(k)
+        vn = kn if v is k else (qn if v is q else _to_nhwc(v))
+        out = torch.empty((b, h, w, c), dtype=torch.float32, device=q.device)
+        desc = self._desc()
+        lib = L.lib()
+        ws, wsn = _workspace(lib.swf_window_attention_workspace_bytes(C.byref(desc), b, h, w), q.device)
+        prm = self._params()
+        L.check(lib.swf_window_attention_fwd(C.byref(desc), C.byref(prm), _ptr(qn), _ptr(kn), _ptr(vn), None,
+                                             _ptr(out), b, h, w, ws, wsn, _stream(q.device)))
+        return _to_nchw(out)
+
+
+# ----------------------------------------------------------------------------------------------
+# a002 / a003: dual-stream routing of attention and MLP
+# ----------------------------------------------------------------------------------------------
+class AutoPathWinAtt(_FwdAlias, nn.Module):
+    """a002_AutoPathWinAtt.AutoPathWinAtt: two WindowAttentions, self or cross routing (a002:58-82)."""
+
+    def __init__(self, in_out_dims: int, num_heads: int, dims_per_head: int, window_size: tuple,
+                 use_cyclic_shift: bool, use_dual_path: bool, use_cross_att: bool, use_qkv_bias: bool,
+                 attention_drop_ratio: float, linear_after_att_drop_ratio: float):
+        super().__init__()
+        self.in_out_dims, self.num_heads, self.dims_per_head = in_out_dims, num_heads, dims_per_head
+        self.window_size = tuple(window_size)
+        self.use_cyclic_shift, self.use_dual_path, self.use_cross_att = use_cyclic_shift, use_dual_path, use_cross_att
+        self.use_qkv_bias = use_qkv_bias
+        self.attention_drop_ratio, self.linear_after_att_drop_ratio = attention_drop_ratio, linear_after_att_drop_ratio
+        mk = lambda: WindowAttention(in_out_dims, num_heads, dims_per_head, window_size, use_cyclic_shift,
+                                     use_cross_att, use_qkv_bias, attention_drop_ratio, linear_after_att_drop_ratio)
+        self.window_attention_x = mk()
+        if use_dual_path:
+            self.window_attention_y = mk()
+
+    def forward(self, x, y):
+        if not self.use_dual_path:
+            return self.window_attention_x(q=x, k=x, v=x)
+        if self.use_cross_att:
+            return self.window_attention_x(q=x, k=y, v=y), self.window_attention_y(q=y, k=x, v=x)
+        return self.window_attention_x(q=x, k=x, v=x), self.window_attention_y(q=y, k=y, v=y)
+
+
+class AutoPathMLP(_FwdAlias, nn.Module):
+    """a003_AutoPathMLP.AutoPathMLP: per-stream 1x1 conv -> activation -> 1x1 conv (a003:21-50)."""
+
+    def __init__(self, in_out_dims: int, hidden_dims: int, activation_func: nn.Module, use_dual_path: bool,
+                 drop_ratio: float):
+        super().__init__()
+        self.in_out_dims, self.hidden_dims, self.activation_func = in_out_dims, hidden_dims, activation_func
+        self.use_dual_path, self.drop_ratio = use_dual_path, drop_ratio
+        for s in ("x", "y") if use_dual_path else ("x",):
+            c1 = nn.Conv2d(in_out_dims, hidden_dims, kernel_size=1)
+            c2 = nn.Conv2d(hidden_dims, in_out_dims, kernel_size=1)
+            d1, d2 = nn.Dropout(p=drop_ratio), nn.Dropout(p=drop_ratio)
+            setattr(self, f"mlp_{s}_1", c1)
+            setattr(self, f"mlp_{s}_2", c2)
+            setattr(self, f"dropout_{s}_1", d1)
+            setattr(self, f"dropout_{s}_2", d2)
+            setattr(self, f"sequence_{s}", nn.Sequential(c1, activation_func, d1, c2, d2))
+
+    def _one(self, t: Tensor, s: str) -> Tensor:
+        _require_elu(self.activation_func)
+        if self.training and self.drop_ratio:
+            raise NotImplementedError("dropout > 0 in training mode is outside the forward-only HIP path")
+        b, c, h, w = t.shape
+        tn = _to_nhwc(t)
+        lib = L.lib()
+        hid = torch.empty((b, h, w, self.hidden_dims), dtype=torch.float32, device=t.device)
+        out = torch.empty((b, h, w, c), dtype=torch.float32, device=t.device)
+        l1, l2 = _lin(getattr(self, f"mlp_{s}_1")), _lin(getattr(self, f"mlp_{s}_2"))
+        n = b * h * w
+        L.check(lib.swf_linear_fwd(C.byref(l1), _ptr(tn), None, _ptr(hid), n, c, self.hidden_dims, 1, _stream(t.device)))
+        L.check(lib.swf_linear_fwd(C.byref(l2), _ptr(hid), None, _ptr(out), n, self.hidden_dims, c, 0, _stream(t.device)))
+        return _to_nchw(out)
+
+    def forward(self, x, y):
+        _check_forward_only(self, x, y)
+        if self.use_dual_path or y is not None:
+            return self._one(x, "x"), self._one(y, "y")
+        return self._one(x, "x")
+
+
+# ----------------------------------------------------------------------------------------------
+# a004: pre-norm residual wrapper
+# ----------------------------------------------------------------------------------------------
+class AddAndLayerNormWithOtherModule(_FwdAlias, nn.Module):
+    """a004: out = x + other(LN_x(x), LN_y(y)) per stream (a004:20-48).  `other_module` must be one of
+    this package's AutoPathWinAtt / AutoPathMLP — those are the two uses in the reference (a005:70-82) and
+    the two fused half-block units of the C-ABI."""
+
+    def __init__(self, normalized_shape: list, use_dual_path: bool, other_module: nn.Module):
+        super().__init__()
+        self.normalized_shape, self.use_dual_path, self.other_module = normalized_shape, use_dual_path, other_module
+        self.norm_layer_1 = nn.LayerNorm(normalized_shape=normalized_shape)
+        if use_dual_path:
+            self.norm_layer_2 = nn.LayerNorm(normalized_shape=normalized_shape)
+
+    def forward(self, x, y):
+        _check_forward_only(self, x, y)
+        om = self.other_module
+        dual = self.use_dual_path or y is not None
+        b, c, h, w = x.shape
+        xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
+        ox = torch.empty_like(xn)
+        oy = torch.empty_like(yn) if dual else None
+        lib = L.lib()
+        streams = ("x", "y") if dual else ("x",)
+        norms = {"x": self.norm_layer_1, "y": getattr(self, "norm_layer_2", None)}
+        prm = {}
+        if isinstance(om, AutoPathWinAtt):
+            wa0 = om.window_attention_x
+            desc = L.BlockDesc(wa0._desc(), 1, int(bool(om.use_cross_att)), L.PREC_FP32)
+            for s in streams:
+                p = L.BlockStreamParams()
+                p.ln1 = _norm(norms[s])
+                p.attn = getattr(om, f"window_attention_{s}")._params()
+                prm[s] = p
+            fn = lib.swf_attn_halfblock_fwd
+        elif isinstance(om, AutoPathMLP):
+            _require_elu(om.activation_func)
+            desc = L.BlockDesc(L.AttnDesc(om.in_out_dims, 1, 1, 1, 1, 0), om.hidden_dims, 0, L.PREC_FP32)
+            for s in streams:
+                p = L.BlockStreamParams()
+                p.ln2 = _norm(norms[s])
+                p.fc1, p.fc2 = _lin(getattr(om, f"mlp_{s}_1")), _lin(getattr(om, f"mlp_{s}_2"))
+                prm[s] = p
+            fn = lib.swf_mlp_halfblock_fwd
+        else:
+            raise NotImplementedError("other_module must be AutoPathWinAtt or AutoPathMLP of this package")
+        ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(
+            C.byref(L.BlockDesc(desc.attn, max(desc.hidden, 1), 0, L.PREC_FP32)), b, h, w), x.device)
+        L.check(fn(C.byref(desc), C.byref(prm["x"]), C.byref(prm["y"]) if dual else None, _ptr(xn),
+                   _ptr(yn) if dual else None, _ptr(ox), _ptr(oy) if dual else None, b, h, w, ws, wsn, _stream(x.device)))
+        if dual:
+            return _to_nchw(ox), _to_nchw(oy)
+        return _to_nchw(ox)
+
+
+# ----------------------------------------------------------------------------------------------
+# a005 / a009 / a012: blocks
+# ----------------------------------------------------------------------------------------------
+class BasicBlock(_FwdAlias, nn.Module):
+    """a005_BasicBlock.BasicBlock (ctor a005:11-28, forward a005:127-145)."""
+
+    def __init__(self, in_out_dims: int, num_heads: int, dims_per_head: int, window_size: tuple,
+                 use_cyclic_shift: bool, use_dual_path: bool, use_cross_attr: bool, use_qkv_bias: bool,
+                 attention_drop_ratio: float, linear_after_att_drop_ratio: float, mlp_hidden_dims: int,
+                 mlp_activation_func: nn.Module, mlp_drop_ratio: float):
+        super().__init__()
+        self.in_out_dims, self.num_heads, self.dims_per_head = in_out_dims, num_heads, dims_per_head
+        self.window_size = tuple(window_size)
+        self.use_cyclic_shift, self.use_dual_path, self.use_cross_attr = use_cyclic_shift, use_dual_path, use_cross_attr
+        self.use_qkv_bias = use_qkv_bias
+        self.attention_drop_ratio, self.linear_after_att_drop_ratio = attention_drop_ratio, linear_after_att_drop_ratio
+        self.mlp_hidden_dims, self.mlp_activation_func, self.mlp_drop_ratio = mlp_hidden_dims, mlp_activation_func, mlp_drop_ratio
+        self.input_compatibility_with_cross_option = None
+        self.precision = "fast"
+        self.auto_path_win_att = AutoPathWinAtt(in_out_dims, num_heads, dims_per_head, window_size, use_cyclic_shift,
+                                                use_dual_path, use_cross_attr, use_qkv_bias, attention_drop_ratio,
+                                                linear_after_att_drop_ratio)
+        self.auto_path_mlp = AutoPathMLP(in_out_dims, mlp_hidden_dims, mlp_activation_func, use_dual_path, mlp_drop_ratio)
+        # the same sub-modules registered a second time, as in the reference (a005:70-82) -> aliased state_dict keys
+        self.stage_1 = AddAndLayerNormWithOtherModule([in_out_dims], use_dual_path, self.auto_path_win_att)
+        self.stage_2 = AddAndLayerNormWithOtherModule([in_out_dims], use_dual_path, self.auto_path_mlp)
+
+    def check_input_compatibility_with_option(self, x, y):
+        """First-call sanity check of a005:88-125.  The reference prints and calls exit(); this
+        raises ValueError instead (documented deviation)."""
+        if self.input_compatibility_with_cross_option is not None:
+            return
+        ok = x is not None and (y is not None) == bool(self.use_dual_path)
+        if ok and self.use_cross_attr and y is not None and torch.equal(x, y):
+            ok = False
+        if not ok:
+            self.input_compatibility_with_cross_option = False
+            raise ValueError("inputs are incompatible with the cross_attr / dual_path options "
+                             "(y missing or unexpected, or cross attention given identical x and y)")
+        self.input_compatibility_with_cross_option = True
+
+    def _desc(self, precision) -> L.BlockDesc:
+        return L.BlockDesc(self.auto_path_win_att.window_attention_x._desc(), self.mlp_hidden_dims,
+                           int(bool(self.use_cross_attr)), _precision_code(precision))
+
+    def _stream_params(self, s: str) -> L.BlockStreamParams:
+        _require_elu(self.mlp_activation_func)
+        p = L.BlockStreamParams()
+        idx = "1" if s == "x" else "2"
+        p.ln1 = _norm(getattr(self.stage_1, f"norm_layer_{idx}"))
+        p.attn = getattr(self.auto_path_win_att, f"window_attention_{s}")._params()
+        p.ln2 = _norm(getattr(self.stage_2, f"norm_layer_{idx}"))
+        p.fc1, p.fc2 = _lin(getattr(self.auto_path_mlp, f"mlp_{s}_1")), _lin(getattr(self.auto_path_mlp, f"mlp_{s}_2"))
+        return p
+
+    def forward(self, x, y=None):
+        _check_forward_only(self, x, y)
+        self.check_input_compatibility_with_option(x=x, y=y)
+        dual = self.use_dual_path or y is not None
+        b, c, h, w = x.shape
+        xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
+        ox = torch.empty_like(xn)
+        oy = torch.empty_like(yn) if dual else None
+        desc = self._desc(self.precision)
+        px = self._stream_params("x")
+        py = self._stream_params("y") if dual else None
+        lib = L.lib()
+        ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(C.byref(desc), b, h, w), x.device)
+        L.check(lib.swf_basic_block_fwd(C.byref(desc), C.byref(px), C.byref(py) if dual else None, _ptr(xn),
+                                        _ptr(yn) if dual else None, _ptr(ox), _ptr(oy) if dual else None,
+                                        b, h, w, ws, wsn, _stream(x.device)))
+        return (_to_nchw(ox), _to_nchw(oy)) if dual else _to_nchw(ox)
+
+
+class NormalAndShiftWinsBlockPair(_FwdAlias, nn.Module):
+    """a009: BasicBlock(shift=False) then BasicBlock(shift=True) (a009:57-109)."""
+
+    def __init__(self, in_out_dims: int, num_heads: int, dims_per_head: int, window_size: tuple, use_dual_path: bool,
+                 use_cross_attr: bool, use_qkv_bias: bool, attention_drop_ratio: float,
+                 linear_after_att_drop_ratio: float, mlp_hidden_dims: int, mlp_activation_func: nn.Module,
+                 mlp_drop_ratio: float):
+        super().__init__()
+        self.in_out_dims, self.num_heads, self.dims_per_head = in_out_dims, num_heads, dims_per_head
+        self.window_size, self.use_dual_path, self.use_cross_attr = tuple(window_size), use_dual_path, use_cross_attr
+        self.use_qkv_bias = use_qkv_bias
+        self.attention_drop_ratio, self.linear_after_att_drop_ratio = attention_drop_ratio, linear_after_att_drop_ratio
+        self.mlp_hidden_dims, self.mlp_activation_func, self.mlp_drop_ratio = mlp_hidden_dims, mlp_activation_func, mlp_drop_ratio
+        mk = lambda shift: BasicBlock(in_out_dims, num_heads, dims_per_head, window_size, shift, use_dual_path,
+                                      use_cross_attr, use_qkv_bias, attention_drop_ratio, linear_after_att_drop_ratio,
+                                      mlp_hidden_dims, mlp_activation_func, mlp_drop_ratio)
+        self.normal_window_block = mk(False)
+        self.shifted_window_block = mk(True)
+
+    def forward(self, x, y=None):
+        if self.use_dual_path:
+            x, y = self.normal_window_block(x=x, y=y)
+            return self.shifted_window_block(x=x, y=y)
+        x = self.normal_window_block(x=x, y=None)
+        return self.shifted_window_block(x=x, y=None)
+
+
+class SelfAndCrossBlockPair(_FwdAlias, nn.Module):
+    """Drop-in for a012_SelfAndCrossBlockPair.SelfAndCrossBlockPair (ctor a012:10-25, forward a012:70-78):
+    four BasicBlocks — self/normal, self/shifted, cross/normal, cross/shifted — as ONE C-ABI call."""
+
+    def __init__(self, in_out_dims: int, num_heads: int, dims_per_head: int, window_size: tuple, use_dual_path: bool,
+                 use_qkv_bias: bool, attention_drop_ratio: float, linear_after_att_drop_ratio: float,
+                 mlp_hidden_dims: int, mlp_activation_func: nn.Module, mlp_drop_ratio: float):
+        super().__init__()
+        self.in_out_dims, self.num_heads, self.dims_per_head = in_out_dims, num_heads, dims_per_head
+        self.window_size, self.use_dual_path, self.use_qkv_bias = tuple(window_size), use_dual_path, use_qkv_bias
+        self.attention_drop_ratio, self.linear_after_att_drop_ratio = attention_drop_ratio, linear_after_att_drop_ratio
+        self.mlp_hidden_dims, self.mlp_activation_func, self.mlp_drop_ratio = mlp_hidden_dims, mlp_activation_func, mlp_drop_ratio
+        self.precision = "fast"
+        mk = lambda cross: NormalAndShiftWinsBlockPair(in_out_dims, num_heads, dims_per_head, window_size, use_dual_path,
+                                                       cross, use_qkv_bias, attention_drop_ratio,
+                                                       linear_after_att_drop_ratio, mlp_hidden_dims, mlp_activation_func,
+                                                       mlp_drop_ratio)
+        self.self_att_block = mk(False)
+        self.cross_att_block = mk(True)
+
+    def _blocks(self) -> List[BasicBlock]:
+        return [self.self_att_block.normal_window_block, self.self_att_block.shifted_window_block,
+                self.cross_att_block.normal_window_block, self.cross_att_block.shifted_window_block]
+
+    def forward(self, x, y=None):
+        _check_forward_only(self, x, y)
+        blocks = self._blocks()
+        dual = self.use_dual_path
+        if dual and y is None:
+            raise ValueError("use_dual_path=True needs both x and y")
+        blocks[2].check_input_compatibility_with_option(x=x, y=y if dual else None)
+        b, c, h, w = x.shape
+        xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
+        ox = torch.empty_like(xn)
+        oy = torch.empty_like(yn) if dual else None
+        desc = blocks[0]._desc(self.precision)
+        px = (L.BlockStreamParams * 4)(*[blk._stream_params("x") for blk in blocks])
+        py = (L.BlockStreamParams * 4)(*[blk._stream_params("y") for blk in blocks]) if dual else None
+        lib = L.lib()
+        ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(C.byref(desc), b, h, w), x.device)
+        L.check(lib.swf_block_pair4_fwd(C.byref(desc), px, py, _ptr(xn), _ptr(yn) if dual else None, _ptr(ox),
+                                        _ptr(oy) if dual else None, b, h, w, ws, wsn, _stream(x.device)))
+        return (_to_nchw(ox), _to_nchw(oy)) if dual else _to_nchw(ox)
+
+
+# ----------------------------------------------------------------------------------------------
+# a006 / a011: padding and patch (un)merging
+# ----------------------------------------------------------------------------------------------
+class MyPadding(_FwdAlias, nn.Module):
+    """a006_PaddingOperation.MyPadding: encoder side reflect-pads bottom/right to a multiple of
+    `window_size` and pushes (shape, pad) on the shared recorders; decoder side pops and crops."""
+
+    def __init__(self, belongs_to_encoder: bool, window_size: tuple, use_dual_path: bool,
+                 feature_shape_recorder: StateRecorder, padding_size_recorder: StateRecorder):
+        super().__init__()
+        self.belongs_to_encoder, self.window_size, self.use_dual_path = belongs_to_encoder, tuple(window_size), use_dual_path
+        self.feature_shape_hw: tuple = tuple()
+        self.padding_size: tuple = tuple()
+        self.feature_shape_recorder, self.padding_size_recorder = feature_shape_recorder, padding_size_recorder
+
+    @staticmethod
+    def calculate_padding_size(current_length, window_size):
+        return (window_size - current_length % window_size) % window_size
+
+    def _pad(self, t: Tensor) -> Tensor:
+        ph, pw = self.padding_size
+        if ph == 0 and pw == 0:
+            return t
+        b, c, h, w = t.shape
+        t = t.contiguous()
+        out = torch.empty((b, c, h + ph, w + pw), dtype=torch.float32, device=t.device)
+        # an NCHW tensor is B*C single-channel maps in the library's NHWC convention
+        L.check(L.lib().swf_reflect_pad_fwd(_ptr(t), _ptr(out), b * c, h, w, 1, ph, pw, _stream(t.device)))
+        return out
+
+    def _crop(self, t: Tensor) -> Tensor:
+        ph, pw = self.padding_size
+        if ph == 0 and pw == 0:
+            return t
+        b, c, h, w = t.shape
+        t = t.contiguous()
+        out = torch.empty((b, c, h - ph, w - pw), dtype=torch.float32, device=t.device)
+        L.check(L.lib().swf_crop_fwd(_ptr(t), _ptr(out), b * c, h, w, h - ph, w - pw, 1, _stream(t.device)))
+        return out
+
+    def forward(self, x, y):
+        _check_forward_only(self, x, y)
+        if self.belongs_to_encoder:
+            h, w = x.shape[-2:]
+            if not (self.training and self.feature_shape_hw):   # a006:38-52: refreshed every call in eval
+                self.feature_shape_hw = (h, w)
+            self.feature_shape_recorder.record(self.feature_shape_hw)
+            if not (self.training and self.padding_size):
+                fh, fw = self.feature_shape_hw
+                self.padding_size = (self.calculate_padding_size(fh, self.window_size[0]),
+                                     self.calculate_padding_size(fw, self.window_size[1]))
+            self.padding_size_recorder.record(self.padding_size)
+            op = self._pad
+        else:
+            self.feature_shape_hw = self.feature_shape_recorder.read()
+            self.padding_size = self.padding_size_recorder.read()
+            op = self._crop
+        if self.use_dual_path:
+            return op(x), (op(y) if y is not None else None)
+        return op(x)
+
+
+class PatchMergingAndLinearLayer(_FwdAlias, nn.Module):
+    """a011_PatchOperation.PatchMergingAndLinearLayer (ctor a011:26-70, forward a011:244-264)."""
+
+    def __init__(self, belongs_to_encoder: bool, use_dual_path: bool, in_dims: int, out_dims: int,
+                 patch_merging_size_recorder: StateRecorder, merging_or_unmerging_size: tuple,
+                 activation_func: nn.Module = nn.ELU()):
+        super().__init__()
+        self.belongs_to_encoder, self.use_dual_path = belongs_to_encoder, use_dual_path
+        self.in_dims, self.out_dims = in_dims, out_dims
+        self.patch_merging_recorder = patch_merging_size_recorder
+        self.merging_or_unmerging_size = tuple(merging_or_unmerging_size)
+        self.activation_func = activation_func
+        ratio = self.merging_or_unmerging_size[0] * self.merging_or_unmerging_size[1]
+        self.conv_in_dims = in_dims * ratio if belongs_to_encoder else in_dims
+        self.conv_out_dims = out_dims if belongs_to_encoder else out_dims * ratio
+        self.mlp_layer_x = nn.Conv2d(self.conv_in_dims, self.conv_out_dims, kernel_size=1)
+        self.layer_norm_x = nn.LayerNorm(normalized_shape=self.conv_out_dims)
+        if use_dual_path:
+            self.mlp_layer_y = nn.Conv2d(self.conv_in_dims, self.conv_out_dims, kernel_size=1)
+            self.layer_norm_y = nn.LayerNorm(normalized_shape=self.conv_out_dims)
+        self.register_buffer(name="buffer_to_show_device", tensor=torch.zeros(size=(1,)))
+
+    def _one(self, t: Tensor, s: str) -> Tensor:
+        _require_elu(self.activation_func)
+        b, c, h, w = t.shape
+        mh, mw = self.merging_or_unmerging_size
+        prm = L.PatchParams(_lin(getattr(self, f"mlp_layer_{s}")), _norm(getattr(self, f"layer_norm_{s}")))
+        tn = _to_nhwc(t)
+        lib = L.lib()
+        if self.belongs_to_encoder:
+            if h % mh or w % mw:   # einops raises in the reference (a011:87-93); MyPadding runs first in the model
+                raise ValueError(f"map {h}x{w} is not divisible by the merging size {mh}x{mw}")
+            out = torch.empty((b, h // mh, w // mw, self.out_dims), dtype=torch.float32, device=t.device)
+            ws, wsn = _workspace(lib.swf_patch_workspace_bytes(b, h, w, self.in_dims, self.out_dims, mh, mw, 1, 1, 1), t.device)
+            L.check(lib.swf_patch_merge_fwd(C.byref(prm), _ptr(tn), _ptr(out), b, h, w, self.in_dims, self.out_dims,
+                                            mh, mw, 1, 1, ws, wsn, _stream(t.device)))
+        else:
+            out = torch.empty((b, h * mh, w * mw, self.out_dims), dtype=torch.float32, device=t.device)
+            ws, wsn = _workspace(lib.swf_patch_workspace_bytes(b, h, w, self.in_dims, self.out_dims, mh, mw, 1, 1, 0), t.device)
+            L.check(lib.swf_patch_unmerge_fwd(C.byref(prm), _ptr(tn), None, _ptr(out), b, h, w, h, w, self.in_dims,
+                                              self.out_dims, mh, mw, h * mh, w * mw, ws, wsn, _stream(t.device)))
+        return _to_nchw(out)
+
+    def forward(self, x, y=None):
+        _check_forward_only(self, x, y)
+        if x.shape[1] != self.in_dims:
+            raise RuntimeError(f"expected {self.in_dims} channels, got {x.shape[1]}")
+        if y is not None:
+            return self._one(x, "x"), self._one(y, "y")
+        return self._one(x, "x")
+
+
+# ----------------------------------------------------------------------------------------------
+# a013: model assembly
+# ----------------------------------------------------------------------------------------------
+def get_encoder_or_decoder_block(mode: str, window_size: tuple, feature_shape_recorder: StateRecorder,
+                                 padding_size_recorder: StateRecorder, merging_size: tuple, in_dims: int, out_dims: int,
+                                 patch_merging_size_recorder: StateRecorder, att_num_heads: int, att_dims_per_head: int,
+                                 attention_drop_ratio: float, linear_after_att_drop_ratio: float, mlp_hidden_dims: int,
+                                 mlp_activation_func: nn.Module, mlp_drop_ratio: float) -> nn.ModuleList:
+    """a013:236-314: [pad(merge), merge, pad(window), blocks] for the encoder, the same four in
+    reverse for the decoder; attention width is out_dims (encoder) / in_dims (decoder)."""
+    if mode not in ("encoder", "decoder"):
+        raise ValueError("mode must be either encoder or decoder")
+    enc = mode == "encoder"
+    mods = [
+        MyPadding(enc, merging_size, True, feature_shape_recorder, padding_size_recorder),
+        PatchMergingAndLinearLayer(enc, True, in_dims, out_dims, patch_merging_size_recorder, merging_size,
+                                   mlp_activation_func),
+        MyPadding(enc, window_size, True, feature_shape_recorder, padding_size_recorder),
+        SelfAndCrossBlockPair(out_dims if enc else in_dims, att_num_heads, att_dims_per_head, window_size, True, True,
+                              attention_drop_ratio, linear_after_att_drop_ratio, mlp_hidden_dims, mlp_activation_func,
+                              mlp_drop_ratio),
+    ]
+    return nn.ModuleList(mods if enc else mods[::-1])
+
+
+class MyModel(_FwdAlias, nn.Module):
+    """Drop-in for a013_ModelDefinition.MyModel (ctor a013:18-38, forward a013:209-230).
+
+    `forward(in_x, in_y)` is ONE call into the C-ABI (`swf_model_forward`): the parameters are
+    copied once into a flat device arena whose layout the library defines by state_dict key
+    (`swf_model_param_info`), and the whole U-Net runs from that arena on the current stream.
+    `precision` ('fast' | 'fp32') selects the arithmetic mode (include/swinfuse.h swf_precision).
+    """
+
+    def __init__(self, window_size: tuple, merging_size: tuple, in_dims_list: list, out_dims_list: list,
+                 att_num_heads: int, att_dims_per_head_ratio: float, attention_drop_ratio: float,
+                 linear_after_att_drop_ratio: float, mlp_hidden_dims_ratio: int, mlp_activation_func: nn.Module,
+                 mlp_drop_ratio: float, final_layer_att_dims_per_head_ratio: float, final_conv_layer_kernel_size: int,
+                 final_layer_mlp_hidden_dims_ratio: int):
+        super().__init__()
+        self.window_size, self.merging_size = tuple(window_size), tuple(merging_size)
+        self.in_dims_list, self.out_dims_list = list(in_dims_list), list(out_dims_list)
+        self.att_num_heads, self.att_dims_per_head_ratio = att_num_heads, att_dims_per_head_ratio
+        self.attention_drop_ratio, self.linear_after_att_drop_ratio = attention_drop_ratio, linear_after_att_drop_ratio
+        self.mlp_hidden_dims_ratio, self.mlp_activation_func, self.mlp_drop_ratio = mlp_hidden_dims_ratio, mlp_activation_func, mlp_drop_ratio
+        self.final_layer_att_dims_per_head_ratio = final_layer_att_dims_per_head_ratio
+        self.final_layer_conv_kernel_size = final_conv_layer_kernel_size
+        self.final_layer_mlp_hidden_dims_ratio = final_layer_mlp_hidden_dims_ratio
+        self.feature_shape_recorder, self.padding_size_recorder = StateRecorder(), StateRecorder()
+        self.patch_merging_size_recorder, self.u_net_intermediate_result_recorder = StateRecorder(), StateRecorder()
+        self.precision = "fast"
+        self._arena: Optional[Tensor] = None
+        self._arena_key = None
+
+        enc, dec = deque(), deque()
+        for j in range(len(self.in_dims_list) - 1, -1, -1):   # a013:154-207
+            common = dict(window_size=self.window_size, feature_shape_recorder=self.feature_shape_recorder,
+                          padding_size_recorder=self.padding_size_recorder, merging_size=self.merging_size,
+                          patch_merging_size_recorder=self.patch_merging_size_recorder, att_num_heads=att_num_heads,
+                          att_dims_per_head=math.floor(self.out_dims_list[j] * att_dims_per_head_ratio),
+                          attention_drop_ratio=attention_drop_ratio, linear_after_att_drop_ratio=linear_after_att_drop_ratio,
+                          mlp_activation_func=mlp_activation_func, mlp_drop_ratio=mlp_drop_ratio)
+            enc.appendleft(get_encoder_or_decoder_block(mode="encoder", in_dims=self.in_dims_list[j],
+                                                        out_dims=self.out_dims_list[j],
+                                                        mlp_hidden_dims=self.out_dims_list[j] * mlp_hidden_dims_ratio, **common))
+            dec.append(get_encoder_or_decoder_block(mode="decoder", in_dims=self.out_dims_list[j],
+                                                    out_dims=self.in_dims_list[j],
+                                                    mlp_hidden_dims=self.in_dims_list[j] * mlp_hidden_dims_ratio, **common))
+        self.encoder_list, self.decoder_list = nn.ModuleList(enc), nn.ModuleList(dec)
+        k = final_conv_layer_kernel_size
+        self.final_layer = nn.Sequential(   # a013:98-148
+            nn.Conv2d(2, 2, kernel_size=k, padding="same", padding_mode="reflect"),
+            nn.BatchNorm2d(2),
+            mlp_activation_func,
+            nn.Conv2d(2, 1, kernel_size=k, padding="same", padding_mode="reflect"),
+        )
+        self.register_load_state_dict_post_hook(lambda module, incompatible: module.refresh_weights())
+
+    # ---- weight arena ---------------------------------------------------------------------------
+    def _model_desc(self) -> L.ModelDesc:
+        n = len(self.in_dims_list)
+        if n > L.SWF_MAX_LEVELS:
+            raise NotImplementedError(f"at most {L.SWF_MAX_LEVELS} levels")
+        d = L.ModelDesc()
+        d.levels = n
+        for j in range(n):
+            d.in_dims[j], d.out_dims[j] = self.in_dims_list[j], self.out_dims_list[j]
+            d.head_dim[j] = math.floor(self.out_dims_list[j] * self.att_dims_per_head_ratio)
+        d.heads, d.mlp_ratio = self.att_num_heads, self.mlp_hidden_dims_ratio
+        d.win_h, d.win_w = self.window_size
+        d.merge_h, d.merge_w = self.merging_size
+        d.head_ksize = self.final_layer_conv_kernel_size
+        d.precision = _precision_code(self.precision)
+        return d
+
+    def refresh_weights(self) -> None:
+        """Drop the packed arena; it is rebuilt from the current parameters at the next forward.
+        Called automatically after load_state_dict() and .to(); call it by hand after editing
+        parameters in place."""
+        self._arena, self._arena_key = None, None
+
+    def _apply(self, fn, *a, **kw):
+        self._arena, self._arena_key = None, None
+        return super()._apply(fn, *a, **kw)
+
+    def param_layout(self):
+        """[(state_dict key, element offset, numel)] of the arena, as defined by the library."""
+        lib, desc = L.lib(), self._model_desc()
+        n = lib.swf_model_param_count(C.byref(desc))
+        if n < 0:
+            L.check(L.ERR_BAD_SHAPE)
+        buf = C.create_string_buffer(512)
+        off, num = C.c_int64(), C.c_int64()
+        out = []
+        for i in range(n):
+            L.check(lib.swf_model_param_info(C.byref(desc), i, buf, 512, C.byref(off), C.byref(num)))
+            out.append((buf.value.decode(), off.value, num.value))
+        return out
+
+    def _get_arena(self, device) -> Tensor:
+        key = (torch.device(device).index,)
+        if self._arena is None or self._arena_key != key:
+            _require_elu(self.mlp_activation_func)
+            lib, desc = L.lib(), self._model_desc()
+            total = lib.swf_model_arena_elems(C.byref(desc))
+            sd = self.state_dict()
+            layout = self.param_layout()
+            host = torch.zeros(total, dtype=torch.float32)
+            for name, off, num in layout:
+                t = sd[name]
+                if t.numel() != num:
+                    raise RuntimeError(f"{name}: expected {num} elements, got {t.numel()}")
+                host[off:off + num] = t.detach().reshape(-1).to("cpu", torch.float32)
+            self._arena = host.to(device)
+            self._arena_key = key
+        return self._arena
+
+    # ---- forward ----------------------------------------------------------------------------------
+    def forward(self, in_x: Tensor, in_y: Tensor) -> Tensor:
+        _check_forward_only(self, in_x, in_y)
+        if self.training:
+            raise RuntimeError("MyModel's HIP path is the eval() forward (BatchNorm running statistics, "
+                               "a013:133); call model.eval()")
+        if in_x.shape != in_y.shape or in_x.shape[1] != self.in_dims_list[0]:
+            raise ValueError(f"expected two (B,{self.in_dims_list[0]},H,W) tensors, got {tuple(in_x.shape)} and {tuple(in_y.shape)}")
+        self.u_net_intermediate_result_recorder.delete_all()
+        b, _, h, w = in_x.shape
+        x, y = in_x.contiguous(), in_y.contiguous()
+        arena = self._get_arena(x.device)
+        out = torch.empty((b, 1, h, w), dtype=torch.float32, device=x.device)
+        lib, desc = L.lib(), self._model_desc()
+        need = lib.swf_model_workspace_bytes(C.byref(desc), b, h, w)
+        ws, wsn = _workspace(need, x.device)
+        L.check(lib.swf_model_forward(C.byref(desc), _ptr(arena), _ptr(x), _ptr(y), _ptr(out), b, h, w, ws, wsn,
+                                      _stream(x.device)))
+        return out
