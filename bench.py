@@ -1,0 +1,199 @@
+"""bench.py — fused image-pairs/s of the Swin-UNet fusion forward path on MI355X.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+One step = one MyModel.forward (the whole hot path, through the C-ABI) over one batch of synthetic
+IR/visible pairs already resident in HBM, plus — for N > 1 — the RCCL all-gather of the fused output
+(SURVEY.md §8e).  Weak scaling: every GPU processes `--batch` pairs (BASELINE.json config 4 = 16 x 8).
+Rank 0 prints ONE JSON line.  `roofline` is measured live with HIP events on the launch stream around
+the dominant unit (the level-0 window-attention BasicBlock launch); `cpu_baseline` times the CPU oracle
+(a port of the reference's PyTorch-CPU path) on a bounded sample on rank 0 at N=1.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+REPO = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, REPO)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+from torch import nn  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
+BYTES_PER_ELEM = 4          # the residual stream is stored fp32 (DESIGN.md "Data layout")
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=16, help="pairs per GPU (BASELINE configs 2/4)")
+    ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--config", default="win8")
+    ap.add_argument("--precision", default="fast", choices=["fast", "fp32"])
+    ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs per CPU-baseline forward")
+    ap.add_argument("--cpu-iters", type=int, default=3)
+    return ap.parse_args()
+
+
+def level0_block_roofline(model, batch, size, precision, iters=20):
+    """Time the dominant unit — the level-0 BasicBlock (window attention + MLP on the full-resolution
+    C=out_dims[0] map, both streams) — alone, with HIP events on the launch stream, and price it against
+    HBM.  Algorithmic bytes per launch (attention half-block, both streams, e=4):
+    4*N*C*e + weights.  The fused kernel reads and writes each stream once, so the MLP half adds none."""
+    from swin_unet_image_fusion_amd import _lib as L
+    from swin_unet_image_fusion_amd.modules import _precision_code, _ptr, _stream, _workspace
+
+    blk = model.encoder_list[0][3].self_att_block.shifted_window_block
+    c = blk.in_out_dims
+    mh, mw = model.merging_size
+    h, w = size // mh, size // mw
+    dev = torch.device("cuda", torch.cuda.current_device())
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(batch, h, w, c, generator=g).to(dev)
+    y = torch.randn(batch, h, w, c, generator=g).to(dev)
+    ox, oy = torch.empty_like(x), torch.empty_like(y)
+    lib = L.lib()
+    desc = blk._desc(precision)
+    px, py = blk._stream_params("x"), blk._stream_params("y")
+    ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(C.byref(desc), batch, h, w), dev)
+    stream = _stream(dev)
+
+    def run():
+        L.check(lib.swf_basic_block_fwd(C.byref(desc), C.byref(px), C.byref(py), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy),
+                                        batch, h, w, ws, wsn, stream))
+    for _ in range(3):
+        run()
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        run()
+    e1.record()
+    torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / iters
+    n_tok = batch * h * w
+    hd = blk.num_heads * blk.dims_per_head
+    tbl = (2 * blk.window_size[0] - 1) * (2 * blk.window_size[1] - 1)
+    weight_bytes = 2 * (4 * c * hd + 3 * hd + c + tbl + 2 * c) * 4
+    alg_bytes = 4 * n_tok * c * BYTES_PER_ELEM + weight_bytes
+    achieved = alg_bytes / (ms * 1e-3) / 1e9
+    return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "kernel": "level-0 shifted-window BasicBlock launch (swf_basic_block_fwd)",
+            "ms_per_launch": round(ms, 4), "algorithmic_bytes": alg_bytes, "bytes_per_elem": BYTES_PER_ELEM}
+
+
+def cpu_baseline(cfg, size, pairs, iters):
+    """The CPU oracle (port of the reference's PyTorch-CPU forward, pinned to the reference by
+    tests/test_oracle_golden.py) on the host cores, bounded sample of the same workload."""
+    from oracle import swin_fusion_oracle as O   # bench's cpu_baseline leg is allowed to use the checker
+    from swin_unet_image_fusion_amd import MyModel, load_recipe_into, synthetic_pair
+    m = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True))).eval()
+    load_recipe_into(m, seed=0, flavor="default")
+    sd = {k: v.detach() for k, v in m.state_dict().items()}
+    ir, vis = (torch.from_numpy(a) for a in synthetic_pair(pairs, size, size))
+    # the GPU box gives one GPU a 16-core CPU share although os.cpu_count() reports the whole host:
+    # more threads than that oversubscribe and slow the baseline down (measured: 128 threads -> 0.41 pairs/s)
+    threads = min(len(os.sched_getaffinity(0)), int(os.environ.get("SWF_CPU_THREADS", "16")))
+    torch.set_num_threads(threads)
+    with torch.no_grad():
+        O.model_forward(sd, cfg, ir[:1], vis[:1])   # warm-up
+        best = float("inf")
+        for _ in range(iters):
+            t = time.perf_counter()
+            O.model_forward(sd, cfg, ir, vis)
+            best = min(best, time.perf_counter() - t)
+    return {"value": round(pairs / best, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
+            "sample": f"{iters} forwards of {pairs} pairs {size}x{size} (min), fp32, torch CPU oracle, {threads} threads"}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)   # RCCL
+
+    import __graft_entry__ as entry
+    if rank == 0:
+        entry.build()
+    if world > 1:
+        dist.barrier()
+    from swin_unet_image_fusion_amd import CONFIGS, MyModel, load_recipe_into, synthetic_pair
+    from swin_unet_image_fusion_amd.shard import ShardedFusion
+
+    cfg = CONFIGS[args.config]
+    torch.set_grad_enabled(False)
+    model = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True))).eval()
+    load_recipe_into(model, seed=0, flavor="default")     # random-init weights of the named architecture
+    model.to(dev)
+    model.precision = args.precision
+    runner = ShardedFusion(model, world_size=world, rank=rank, use_graph=not args.no_graph)
+
+    # synthetic IR / visible pairs, distinct per rank, resident in HBM before the timed region
+    ir, vis = synthetic_pair(args.batch, args.size, args.size, seed_ir=1 + 2 * rank, seed_vis=2 + 2 * rank)
+    ir, vis = torch.from_numpy(ir).to(dev), torch.from_numpy(vis).to(dev)
+
+    for _ in range(max(args.warmup, 1)):
+        fused = runner.step(ir, vis)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fused = runner.step(ir, vis)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert fused.shape[0] == args.batch * world and bool(torch.isfinite(fused).all())
+
+    if rank == 0:
+        total_pairs = args.batch * world * args.steps
+        line = {
+            "metric": "fused image-pairs/sec at 256x256, win=8", "value": round(total_pairs / elapsed, 2),
+            "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "bf16" if args.precision == "fast" else "f32", "data": "synthetic",
+            "config": {"workload": f"B={args.batch}/GPU {args.size}x{args.size} IR/visible pairs, win={cfg.window_size[0]}, "
+                                   f"5-level Swin-UNet fusion forward (BASELINE configs[1]; configs[3] at N=8)",
+                       "global_batch": args.batch * world, "precision_mode": args.precision,
+                       "residual_stream": "fp32", "hip_graph": runner.graph_active,
+                       "collective": "rccl all_gather of the fused output" if world > 1 else "none",
+                       "weights": "random-init (numpy PCG64 recipe, seed 0)"},
+        }
+        line["roofline"] = level0_block_roofline(model, args.batch, args.size, args.precision)
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.cpu_pairs, args.cpu_iters)
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,108 @@
+"""Multi-GPU execution of the fusion forward: one process per GPU, batch sharding, one collective.
+
+The reference has no distributed code.  In eval mode nothing couples samples
+(LayerNorm per token, attention per window, BatchNorm running statistics), so image pairs shard
+across ranks with replicated weights and the only exchange is an all-gather of the fused
+(B/G,1,H,W) outputs — RCCL over xGMI when the backend is "nccl" (SURVEY.md §8e).  The same class
+runs under gloo on CPU with any forward callable, which is how the N>1 path is tested without GPUs.
+"""
+from __future__ import annotations
+
+from typing import Callable, Optional, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int, int]:
+    """Contiguous split of `batch` pairs over `world_size` ranks -> (start, stop, padded_shard).
+    Shards are ceil(batch/world) wide; trailing ranks may be short (or empty) and are padded for the
+    collective, which needs equal contributions."""
+    if batch < 0 or world_size <= 0 or not 0 <= rank < world_size:
+        raise ValueError(f"bad shard request batch={batch} world={world_size} rank={rank}")
+    per = -(-batch // world_size) if batch else 0
+    start = min(rank * per, batch)
+    stop = min(start + per, batch)
+    return start, stop, per
+
+
+class ShardedFusion:
+    """step(ir, vis): run this rank's pairs and return the fused output of ALL ranks, rank-major.
+
+    forward_fn defaults to `model(ir, vis)` (the HIP path).  With `use_graph` the forward is captured
+    once per input shape into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed: ~300 kernel
+    launches per forward collapse into one graph launch.  The collective stays outside the graph."""
+
+    def __init__(self, model=None, world_size: int = 1, rank: int = 0, use_graph: bool = False,
+                 forward_fn: Optional[Callable] = None, group=None):
+        self.model, self.world_size, self.rank, self.group = model, world_size, rank, group
+        self.forward_fn = forward_fn or (lambda a, b: model(a, b))
+        self.use_graph = use_graph
+        self.graph_active = False
+        self._graph = None
+        self._static = None   # (ir, vis, out) of the captured graph
+        self._gathered = None
+
+    # -- forward of the local shard --------------------------------------------------------------
+    def _capture(self, ir, vis):
+        self.forward_fn(ir, vis)                      # warm-up: sizes the workspace, builds the arena
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        s = torch.cuda.Stream(device=ir.device)
+        s.wait_stream(torch.cuda.current_stream(ir.device))
+        with torch.cuda.stream(s):
+            self.forward_fn(ir, vis)                  # warm-up on the capture stream (its own workspace)
+            torch.cuda.synchronize()
+            with torch.cuda.graph(g, stream=s):
+                out = self.forward_fn(ir, vis)
+        torch.cuda.current_stream(ir.device).wait_stream(s)
+        self._graph, self._static, self.graph_active = g, (ir, vis, out), True
+
+    def local_forward(self, ir, vis):
+        if not (self.use_graph and ir.is_cuda):
+            return self.forward_fn(ir, vis)
+        if self._static is None or self._static[0].shape != ir.shape:
+            self._capture(ir, vis)
+        s_ir, s_vis, s_out = self._static
+        if s_ir.data_ptr() != ir.data_ptr():
+            s_ir.copy_(ir)
+        if s_vis.data_ptr() != vis.data_ptr():
+            s_vis.copy_(vis)
+        self._graph.replay()
+        return s_out
+
+    # -- collective ------------------------------------------------------------------------------
+    def gather(self, local_out: torch.Tensor) -> torch.Tensor:
+        if self.world_size == 1:
+            return local_out
+        shape = (self.world_size * local_out.shape[0],) + tuple(local_out.shape[1:])
+        if self._gathered is None or self._gathered.shape != shape or self._gathered.device != local_out.device:
+            self._gathered = torch.empty(shape, dtype=local_out.dtype, device=local_out.device)
+        local_out = local_out.contiguous()
+        if local_out.is_cuda:
+            dist.all_gather_into_tensor(self._gathered, local_out, group=self.group)
+        else:   # gloo
+            dist.all_gather(list(self._gathered.chunk(self.world_size, dim=0)), local_out, group=self.group)
+        return self._gathered
+
+    def step(self, ir_shard: torch.Tensor, vis_shard: torch.Tensor) -> torch.Tensor:
+        return self.gather(self.local_forward(ir_shard, vis_shard))
+
+    def fuse_global(self, ir: torch.Tensor, vis: torch.Tensor) -> torch.Tensor:
+        """Every rank passes the same global batch; returns the full fused batch on every rank."""
+        b = ir.shape[0]
+        start, stop, per = shard_bounds(b, self.world_size, self.rank)
+        if per == 0:
+            return ir.new_empty((0, 1) + tuple(ir.shape[2:]))
+        li, lv = ir[start:stop], vis[start:stop]
+        if stop - start < per:    # pad short shards by repeating the last available pair; trimmed below
+            fill = per - (stop - start)
+            src_i = li[-1:] if stop > start else ir[-1:]
+            src_v = lv[-1:] if stop > start else vis[-1:]
+            li = torch.cat([li, src_i.expand(fill, *src_i.shape[1:])])
+            lv = torch.cat([lv, src_v.expand(fill, *src_v.shape[1:])])
+        out = self.step(li.contiguous(), lv.contiguous())
+        if self.world_size == 1:
+            return out[:b]
+        keep = [out[r * per: r * per + max(0, min(per, b - r * per))] for r in range(self.world_size)]
+        return torch.cat(keep)
