@@ -6,9 +6,18 @@ namespace swf {
 
 // true when the fused window-block kernel covers this (dims, map) combination
 bool window_block_supported(const swf_block_desc& d, int B, int H, int W);
+// bytes of the packed (kernel-layout) weights of ONE stream of one block; 0 if unsupported
+size_t window_block_packed_bytes(const swf_block_desc& d);
+// workspace needed by the block-level entry (packs both streams per call)
 size_t window_block_workspace_bytes(const swf_block_desc& d, int B, int H, int W);
-int launch_window_block(const swf_block_desc& d, const swf_block_stream_params& px, const swf_block_stream_params& py,
+
+// fp32 parameters -> kernel layout (split-bf16 hi/lo weight images, pre-scaled Wq, the four
+// masked/unmasked relative-position bias matrices).  One launch for both streams.
+int pack_window_block(const swf_block_desc& d, const swf_block_stream_params& px, const swf_block_stream_params& py,
+                      void* packed_x, void* packed_y, hipStream_t stream);
+
+int launch_window_block(const swf_block_desc& d, const void* packed_x, const void* packed_y,
                         const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
-                        void* workspace, size_t workspace_bytes, hipStream_t stream);
+                        hipStream_t stream);
 
 }  // namespace swf

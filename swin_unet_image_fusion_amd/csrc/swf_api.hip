@@ -158,8 +158,14 @@ static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_p
                             const swf_block_stream_params* py, const float* x_in, const float* y_in, float* x_out,
                             float* y_out, int B, int H, int W, void* workspace, size_t workspace_bytes,
                             hipStream_t stream) {
-    if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W))
-        return launch_window_block(*desc, *px, *py, x_in, y_in, x_out, y_out, B, H, W, workspace, workspace_bytes, stream);
+    if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W)) {
+        // block-level entry: pack this block's weights into the workspace, then one fused launch
+        const size_t pb = window_block_packed_bytes(*desc);
+        if (!workspace || workspace_bytes < 2 * pb) return fail(SWF_ERR_WORKSPACE, "fused block workspace too small (need %zu B)", 2 * pb);
+        char* w = static_cast<char*>(workspace);
+        SWF_TRY(pack_window_block(*desc, *px, *py, w, w + pb, stream));
+        return launch_window_block(*desc, w, w + pb, x_in, y_in, x_out, y_out, B, H, W, stream);
+    }
     {
         Carver ws(workspace, workspace_bytes);
         SWF_TRY(attn_halfblock_generic(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, stream));
