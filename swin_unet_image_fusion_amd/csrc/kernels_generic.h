@@ -19,6 +19,15 @@ struct GemmBatch { GemmProb p[kMaxProb]; };
 int launch_gemm_f32(const GemmBatch& batch, int nprob, int M, int N, int K, int lda, int ldo, int act,
                     hipStream_t stream);
 
+// Same contract in fast-tier arithmetic: split-bf16 (bf16x3) operands on the bf16 MFMA, fp32 accumulate.
+int launch_gemm_bf16x3(const GemmBatch& batch, int nprob, int M, int N, int K, int lda, int ldo, int act,
+                       hipStream_t stream);
+inline int launch_gemm(int fast, const GemmBatch& batch, int nprob, int M, int N, int K, int lda, int ldo, int act,
+                       hipStream_t stream) {
+    return fast ? launch_gemm_bf16x3(batch, nprob, M, N, K, lda, ldo, act, stream)
+                : launch_gemm_f32(batch, nprob, M, N, K, lda, ldo, act, stream);
+}
+
 struct LnProb { const float* in; float* out; const float* gamma; const float* beta; };
 struct LnBatch { LnProb p[2]; };
 // LayerNorm over the last dim (eps 1e-5, biased variance), optional ELU on the result.

@@ -116,6 +116,137 @@ int launch_gemm_f32(const GemmBatch& batch, int nprob, int M, int N, int K, int 
 }
 
 // ------------------------------------------------------------------------------------------
+// Fast-tier GEMM: same contract, operands split on the fly into bf16 hi + lo while staging to LDS
+// ("bf16x3": a_lo.w_hi + a_hi.w_lo + a_hi.w_hi on v_mfma_f32_16x16x32_bf16, fp32 accumulate, ~2^-17
+// relative error — fp32-grade at 3/16 of the f32-MFMA cost; gfx950 has no xf32/tf32).
+// 64x64 tile, K staged 32 at a time, next tile's global loads issued before the MFMAs of the current.
+// ------------------------------------------------------------------------------------------
+using bf16_t = __bf16;
+typedef bf16_t bf16x8_t __attribute__((ext_vector_type(8)));
+typedef bf16_t bf16x4_t __attribute__((ext_vector_type(4)));
+constexpr int XBK = 32, XLD = XBK + 8;   // 80-B rows: conflict-free ds_read_b128
+
+__device__ __forceinline__ void split4(const float4 v, bf16x4_t& hi, bf16x4_t& lo) {
+    const float f[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (bf16_t)f[i];
+        lo[i] = (bf16_t)(f[i] - (float)hi[i]);
+    }
+}
+
+__global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmBatch batch, int M, int N, int K, int lda, int ldo,
+                                                           int act, int vecA, int vecW) {
+    const GemmProb pr = batch.p[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) bf16_t As_hi[GBM * XLD], As_lo[GBM * XLD], Ws_hi[GBN * XLD], Ws_lo[GBN * XLD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wr = wave >> 1, wc = wave & 1;
+    const int brow = blockIdx.x * GBM, bcol = blockIdx.y * GBN;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+    // staging: thread -> (row = tid/4 [+0], 8 consecutive k = (tid%4)*8) of the 64x32 A and W tiles
+    const int lr = tid >> 2, lk = (tid & 3) * 8;
+    const int64_t arow = (int64_t)(brow + lr) * lda;
+    const int64_t wrow = (int64_t)(bcol + lr) * K;
+    const bool a_in = (brow + lr) < M, w_in = (bcol + lr) < N;
+    const int fr = lane & 15, fq = lane >> 4;
+
+    auto load8 = [&](const float* base, int64_t row_off, bool in_range, int vec, int gk, float4& v0, float4& v1) {
+        v0 = make_float4(0.f, 0.f, 0.f, 0.f);
+        v1 = v0;
+        if (!in_range) return;
+        if (vec && gk + 8 <= K) {
+            v0 = *reinterpret_cast<const float4*>(base + row_off + gk);
+            v1 = *reinterpret_cast<const float4*>(base + row_off + gk + 4);
+        } else {
+            float t[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) t[i] = (gk + i < K) ? base[row_off + gk + i] : 0.f;
+            v0 = make_float4(t[0], t[1], t[2], t[3]);
+            v1 = make_float4(t[4], t[5], t[6], t[7]);
+        }
+    };
+    auto stash = [&](bf16_t* hi_img, bf16_t* lo_img, const float4& v0, const float4& v1) {
+        bf16x4_t h0, l0, h1, l1;
+        split4(v0, h0, l0);
+        split4(v1, h1, l1);
+        bf16x8_t h, l;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) { h[i] = h0[i]; h[4 + i] = h1[i]; l[i] = l0[i]; l[4 + i] = l1[i]; }
+        *reinterpret_cast<bf16x8_t*>(hi_img + lr * XLD + lk) = h;
+        *reinterpret_cast<bf16x8_t*>(lo_img + lr * XLD + lk) = l;
+    };
+
+    float4 a0, a1, w0, w1;
+    load8(pr.A, arow, a_in, vecA, lk, a0, a1);
+    load8(pr.W, wrow, w_in, vecW, lk, w0, w1);
+    for (int k0 = 0; k0 < K; k0 += XBK) {
+        __syncthreads();   // the previous k-step's fragment reads are done
+        stash(As_hi, As_lo, a0, a1);
+        stash(Ws_hi, Ws_lo, w0, w1);
+        __syncthreads();
+        if (k0 + XBK < K) {   // issue the next tile's loads; they land while the MFMAs run
+            load8(pr.A, arow, a_in, vecA, k0 + XBK + lk, a0, a1);
+            load8(pr.W, wrow, w_in, vecW, k0 + XBK + lk, w0, w1);
+        }
+        bf16x8_t ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            ah[m] = *reinterpret_cast<const bf16x8_t*>(As_hi + (wr * 32 + m * 16 + fr) * XLD + 8 * fq);
+            al[m] = *reinterpret_cast<const bf16x8_t*>(As_lo + (wr * 32 + m * 16 + fr) * XLD + 8 * fq);
+        }
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            bh[n] = *reinterpret_cast<const bf16x8_t*>(Ws_hi + (wc * 32 + n * 16 + fr) * XLD + 8 * fq);
+            bl[n] = *reinterpret_cast<const bf16x8_t*>(Ws_lo + (wc * 32 + n * 16 + fr) * XLD + 8 * fq);
+        }
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al[m], bh[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bl[n], acc[m][n], 0, 0, 0);
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
+            }
+    }
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n) {
+            const int col = bcol + wc * 32 + n * 16 + fr;
+            if (col >= N) continue;
+            const float bv = pr.bias ? pr.bias[col] : 0.f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int row = brow + wr * 32 + m * 16 + fq * 4 + j;
+                if (row >= M) continue;
+                float v = acc[m][n][j] + bv;
+                if (act == 1) v = elu1(v);
+                const int64_t o = (int64_t)row * ldo + col;
+                if (pr.res) v = pr.res[o] + v;
+                pr.out[o] = v;
+            }
+        }
+}
+
+int launch_gemm_bf16x3(const GemmBatch& batch, int nprob, int M, int N, int K, int lda, int ldo, int act,
+                       hipStream_t stream) {
+    if (M <= 0 || N <= 0 || K <= 0) return fail(SWF_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", M, N, K);
+    int vecA = (lda % 4 == 0), vecW = (K % 4 == 0);
+    for (int i = 0; i < nprob; ++i) {
+        if (reinterpret_cast<uintptr_t>(batch.p[i].A) % 16) vecA = 0;
+        if (reinterpret_cast<uintptr_t>(batch.p[i].W) % 16) vecW = 0;
+    }
+    dim3 grid(cdiv(M, GBM), cdiv(N, GBN), nprob);
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, stream, batch, M, N, K, lda, ldo, act, vecA, vecW);
+    return check_launch("gemm_bf16x3");
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm over C per token.  L lanes (power of two) cooperate on a token.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(LnBatch batch, int64_t tokens, int C, int L, int elu) {

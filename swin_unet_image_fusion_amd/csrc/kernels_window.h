@@ -20,4 +20,11 @@ int launch_window_block(const swf_block_desc& d, const void* packed_x, const voi
                         const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
                         hipStream_t stream);
 
+// MFMA attention core on projection buffers (8x8 windows, head_dim in {3,6,12,24,48}); same contract as
+// launch_attn_core of the exact tier, fast-tier arithmetic (bf16 QK^T, fp16 PV, fp32 softmax).
+bool attn_core_mfma_supported(int wh, int ww, int head_dim);
+int launch_attn_core_mfma(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
+                          const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
+                          int heads, int head_dim, int shift, hipStream_t stream);
+
 }  // namespace swf

@@ -17,6 +17,7 @@
 #include "kernels_window.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <mutex>
 
 namespace swf {
@@ -41,12 +42,12 @@ struct Geo {
     static constexpr int C = C_, HID = HID_, T = 64, WH = 8, WW = 8, HEADS = 8, D = C / 8;
     static_assert(C % 8 == 0, "8 heads of C/8 channels");
     static constexpr int KC = cround(C, 32), KH = cround(HID, 32);      // K extents padded to the MFMA k-step
-    static constexpr int LDC = KC + 8, LDH = KH + 8;                    // LDS row strides (bf16): odd multiples of 16 B -> conflict-free b128 reads
+    static constexpr int LDC = KC + 8;                                  // row stride (bf16) of the token-major images: odd multiple of 16 B -> conflict-free b128 reads
     static constexpr int NTC = cceil(C, 16), NTH = cceil(HID, 16);      // 16-wide output tiles
     static constexpr int NH = NTH * 16;
-    static constexpr int QS = cround(D, 8);                             // bf16 slots per (head, token) row of the Q / K images
-    static constexpr int QKS = cceil(D, 16);                            // 16-deep k-steps of Q.K^T
+    static constexpr int NKS = KC / 16;                                 // 16-deep k-steps spanning all channels (Q.K^T walks only those a head touches)
     static constexpr int MT = cceil(D, 32);                             // 32-row M tiles of O^T per head
+    static constexpr int VRS = T + 8;                                   // V^T row stride (halves; 144 B keeps b128 alignment and spreads rows over banks)
 
     // ---- packed weights of one stream.  The first `wsec` bytes are staged verbatim into LDS. ----
     static constexpr size_t p_wqkv_hi = 0, p_wqkv_lo = p_wqkv_hi + size_t(3) * C * KC * 2;     // [3C][KC] bf16 (Wq pre-scaled)
@@ -54,25 +55,22 @@ struct Geo {
     static constexpr size_t p_w1_hi = p_wp_lo + size_t(C) * KC * 2, p_w1_lo = p_w1_hi + size_t(HID) * KC * 2;
     static constexpr size_t p_w2_hi = p_w1_lo + size_t(HID) * KC * 2, p_w2_lo = p_w2_hi + size_t(C) * KH * 2;
     static constexpr size_t p_vec = (p_w2_lo + size_t(C) * KH * 2 + 15) / 16 * 16;             // fp32 vectors
-    static constexpr int v_ln1g = 0, v_ln1b = C, v_ln2g = 2 * C, v_ln2b = 3 * C, v_bqkv = 4 * C, v_bp = 7 * C, v_b2 = 8 * C,
-                         v_b1 = 9 * C, v_end = 9 * C + NH;
+    static constexpr int v_ln1g = 0, v_ln1b = KC, v_ln2g = 2 * KC, v_ln2b = 3 * KC, v_bqkv = 4 * KC, v_bp = v_bqkv + 3 * C, v_b2 = v_bp + C,
+                         v_b1 = v_b2 + C, v_end = v_b1 + KH;
     static constexpr size_t wsec = (p_vec + size_t(v_end) * 4 + 15) / 16 * 16;
     static constexpr size_t p_bias4 = wsec;                                                   // [4 variants][64 keys][64 queries] fp32, global only
     static constexpr size_t p_total = p_bias4 + size_t(4) * T * T * 4;
 
     // ---- LDS carve (bytes) ----
+    static constexpr size_t img = size_t(2) * T * LDC * 2;                // one token-major bf16 image [2 streams][64][LDC]
     static constexpr size_t l_resid = 0;                                  // fp32 [2][64][C]: the residual stream
-    static constexpr size_t l_ahi = l_resid + size_t(2) * T * C * 4;      // bf16 [2][64][LDC]: A-operand image (xn / O / xn2), hi part
-    static constexpr size_t l_alo = l_ahi + size_t(2) * T * LDC * 2;
-    static constexpr size_t l_u = l_alo + size_t(2) * T * LDC * 2;        // union: attention images | MLP hidden images
-    static constexpr size_t l_q = l_u;                                    // bf16 [2][8][64][QS]
-    static constexpr size_t l_k = l_q + size_t(2) * HEADS * T * QS * 2;
-    static constexpr size_t l_vt = l_k + size_t(2) * HEADS * T * QS * 2;  // fp16 [2][8][D][64], keys in MFMA k order
-    static constexpr size_t attn_bytes = size_t(4) * HEADS * T * QS * 2 + size_t(2) * C * T * 2;
-    static constexpr size_t l_hhi = l_u;                                  // bf16 [2][64][LDH]
-    static constexpr size_t l_hlo = l_hhi + size_t(2) * T * LDH * 2;
-    static constexpr size_t mlp_bytes = size_t(4) * T * LDH * 2;
-    static constexpr size_t l_w = (l_u + cmax(attn_bytes, mlp_bytes) + 15) / 16 * 16;   // the two streams' weight sections
+    static constexpr size_t l_ahi = l_resid + size_t(2) * T * C * 4;      // A image (xn / O / xn2 / hidden chunk), hi and lo parts
+    static constexpr size_t l_alo = l_ahi + img;
+    static constexpr size_t l_q = l_alo + img;                            // Q (pre-scaled) and K, bf16, all channels of a token in one row
+    static constexpr size_t l_k = l_q + img;
+    static constexpr size_t l_vt = l_k + img;                             // fp16 [2][C] x VRS: V^T, keys in MFMA k order
+    static constexpr size_t l_mask = l_vt + size_t(2) * C * VRS * 2;      // [8 heads][NKS][2 lane halves] x 16 B: channel masks of a head
+    static constexpr size_t l_w = (l_mask + size_t(HEADS) * NKS * 2 * 16 + 15) / 16 * 16;   // the two streams' weight sections
     static constexpr size_t l_total = l_w + 2 * wsec;
     static_assert(l_total <= 160 * 1024, "window tile + weights exceed the 160 KiB LDS of a CU");
 };
@@ -82,21 +80,38 @@ struct WinArgs {
     float* out[2];
     const char* packed[2];
     int B, H, W, shift, cross;
+    int dbg_skip;   // TEMP ablation mask
 };
 
 // ------------------------------------------------------------------------------------------
 // device helpers
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ float elu_f(float v) { return v > 0.f ? v : expm1f(v); }
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void split_bf16(float v, bf16& hi, bf16& lo) {
-    hi = (bf16)v;
-    lo = (bf16)(v - (float)hi);
+// ELU(alpha=1) for the fast tier: exp(v)-1 through v_exp_f32.  Near 0 the subtraction cancels, leaving an
+// ABSOLUTE error of ~1e-7 on activations of order 1 — four orders below the tier's error budget; the exact
+// tier keeps expm1f.
+__device__ __forceinline__ float elu_fast(float v) { return v > 0.f ? v : __builtin_amdgcn_exp2f(v * kLog2e) - 1.0f; }
+
+// max of three; with -fno-honor-nans hipcc folds this into one v_max3_f32 (and drops the canonicalising
+// v_max it would otherwise put in front of fmaxf on MFMA outputs).  NOT inline asm: an asm statement that
+// reads an MFMA result gets none of the MFMA->VALU wait states and reads stale registers.
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+__device__ __forceinline__ void split4_bf16(const float v[4], bf16x4& hi, bf16x4& lo) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        hi[i] = (bf16)v[i];
+        lo[i] = (bf16)(v[i] - (float)hi[i]);
+    }
 }
 
 // position of key `tok` (0..63) inside a V^T row so that the 8 halves a lane needs for k-step s of
 // key tile T sit contiguously: the S^T accumulator register 8s+e of lane half h is key row
 // 32T + 16s + 8(e>>2) + 4h + (e&3)  (C/D map of the 32x32 MFMA), so pos = 32T + 16s + 8h + e.
+// For tok = 4a .. 4a+3 the positions are consecutive (only e&3 changes): one 8-byte store.
 __device__ __forceinline__ int vt_pos(int tok) {
     const int k16 = tok & 15;
     const int e = ((k16 >> 3) << 2) | (k16 & 3);
@@ -104,77 +119,91 @@ __device__ __forceinline__ int vt_pos(int tok) {
     return (tok & 48) | (h << 3) | e;
 }
 
-// B operand (weights) of one 16-wide output tile, all k-steps, split-bf16: lives in registers while the
-// wave walks the M tiles that share it.
+// split-bf16 operand fragment of one 16-row tile (rows = lanes&15, 8 consecutive k per lane group), all k-steps
 template <int KSTEPS>
-struct BFrag {
+struct Frag {
     bf16x8 hi[KSTEPS], lo[KSTEPS];
 };
 
-template <int KSTEPS, int LDW>
-__device__ __forceinline__ void load_bfrag(BFrag<KSTEPS>& f, const bf16* w_hi, const bf16* w_lo, int row, int g) {
+template <int KSTEPS, int LD>
+__device__ __forceinline__ void load_frag(Frag<KSTEPS>& f, const bf16* hi, const bf16* lo, int row, int g, int k0 = 0) {
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-        f.hi[ks] = *reinterpret_cast<const bf16x8*>(w_hi + row * LDW + ks * 32 + 8 * g);
-        f.lo[ks] = *reinterpret_cast<const bf16x8*>(w_lo + row * LDW + ks * 32 + 8 * g);
+        f.hi[ks] = *reinterpret_cast<const bf16x8*>(hi + row * LD + k0 + ks * 32 + 8 * g);
+        f.lo[ks] = *reinterpret_cast<const bf16x8*>(lo + row * LD + k0 + ks * 32 + 8 * g);
     }
 }
 
-// one 16x16 output tile of A[16 x K] . W[16 x K]^T with split-bf16 operands (three MFMAs per k-step;
-// small cross terms first so they are not absorbed by the large hi.hi partial sums)
-template <int KSTEPS, int LDA>
-__device__ __forceinline__ f32x4 tile_bf16x3(const bf16* a_hi, const bf16* a_lo, const BFrag<KSTEPS>& b, int r, int g) {
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+// D[16 rows of a][16 rows of b] += a . b^T with split-bf16 operands: three MFMAs per k-step, small cross
+// terms first so they are not absorbed by the large hi.hi partial sums.  Result register j of a lane is
+// (a-row 4*(lane>>4)+j, b-row lane&15).
+template <int KSTEPS>
+__device__ __forceinline__ f32x4 mma_bf16x3(const Frag<KSTEPS>& a, const Frag<KSTEPS>& b, f32x4 acc) {
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-        const bf16x8 ah = *reinterpret_cast<const bf16x8*>(a_hi + r * LDA + ks * 32 + 8 * g);
-        const bf16x8 al = *reinterpret_cast<const bf16x8*>(a_lo + r * LDA + ks * 32 + 8 * g);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(al, b.hi[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b.lo[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah, b.hi[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo[ks], b.hi[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi[ks], b.lo[ks], acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi[ks], b.hi[ks], acc, 0, 0, 0);
     }
     return acc;
 }
 
-// LayerNorm of the 128 residual rows (2 streams x 64 tokens) into the split-bf16 A image; 4 lanes per row
+// LayerNorm of the wave's 16 residual rows into its rows of the split-bf16 A image.  4 lanes per row, lane
+// `part` owns the contiguous columns [part*KC/4, (part+1)*KC/4) of the padded row and writes all of them
+// (zeros beyond C) with 16-byte stores.
 template <typename G>
-__device__ __forceinline__ void layernorm_to_image(const float* resid, bf16* ahi, bf16* alo, const float* vec0,
-                                                   const float* vec1, int goff, int boff, int tid) {
-    constexpr int C = G::C, PER = C / 4;
-    const int row = tid >> 2, part = tid & 3;
-    const float* vec = (row >> 6) ? vec1 : vec0;
-    const float* x = resid + row * C;
+__device__ __forceinline__ void layernorm_rows(const float* resid_rows, bf16* ahi_rows, bf16* alo_rows, const float* vec,
+                                               int goff, int boff, int lane) {
+    constexpr int C = G::C, PER = G::KC / 4;
+    static_assert(PER % 8 == 0, "a lane's column run must be whole 16-byte bf16 vectors");
+    const int row = lane >> 2, c0 = (lane & 3) * PER;
+    const float* x = resid_rows + row * C;
     float v[PER];
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) { v[i] = x[part + 4 * i]; sum += v[i]; }
+    for (int i = 0; i < PER; i += 4) {
+        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c0 + i < C) t = *reinterpret_cast<const float4*>(x + c0 + i);   // C % 4 == 0: a float4 is all in or all out
+        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
+        sum += (t.x + t.y) + (t.z + t.w);
+    }
     sum += __shfl_xor(sum, 1);
     sum += __shfl_xor(sum, 2);
     const float mean = sum * (1.0f / C);
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) { const float d = v[i] - mean; var = fmaf(d, d, var); }
+    for (int i = 0; i < PER; ++i) {
+        const float d = (c0 + i < C) ? v[i] - mean : 0.f;
+        var = fmaf(d, d, var);
+    }
     var += __shfl_xor(var, 1);
     var += __shfl_xor(var, 2);
     const float rstd = 1.0f / sqrtf(var * (1.0f / C) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const int c = part + 4 * i;
-        const float n = (v[i] - mean) * rstd * vec[goff + c] + vec[boff + c];
-        bf16 hi, lo;
-        split_bf16(n, hi, lo);
-        ahi[row * G::LDC + c] = hi;
-        alo[row * G::LDC + c] = lo;
+    for (int i = 0; i < PER; i += 8) {
+        bf16x8 h, l;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int c = c0 + i + e;
+            // gamma / beta are stored padded to KC with zeros, so padded columns come out as exact zeros
+            const float n = (v[i + e] - mean) * rstd * vec[goff + c] + vec[boff + c];
+            h[e] = (bf16)n;
+            l[e] = (bf16)(n - (float)h[e]);
+        }
+        *reinterpret_cast<bf16x8*>(ahi_rows + row * G::LDC + c0 + i) = h;
+        *reinterpret_cast<bf16x8*>(alo_rows + row * G::LDC + c0 + i) = l;
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// the block kernel: persistent, one workgroup per CU walks the windows
+// the block kernel: persistent, one workgroup per CU walks the windows.
+// Wave w owns token rows [16*(w&3), +16) of stream w>>2 for every per-token phase (LN, projections, MLP):
+// those phases need no workgroup barrier.  Only attention mixes tokens: one barrier before, one after.
 // ------------------------------------------------------------------------------------------
 template <int C_, int HID_>
 __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
     using G = Geo<C_, HID_>;
-    constexpr int C = G::C, D = G::D, T = G::T, QS = G::QS;
+    constexpr int C = G::C, D = G::D, T = G::T, LDC = G::LDC, KS = G::KC / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* resid = reinterpret_cast<float*>(smem + G::l_resid);
     bf16* ahi = reinterpret_cast<bf16*>(smem + G::l_ahi);
@@ -182,8 +211,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
     bf16* qimg = reinterpret_cast<bf16*>(smem + G::l_q);
     bf16* kimg = reinterpret_cast<bf16*>(smem + G::l_k);
     f16* vt = reinterpret_cast<f16*>(smem + G::l_vt);
-    bf16* hhi = reinterpret_cast<bf16*>(smem + G::l_hhi);
-    bf16* hlo = reinterpret_cast<bf16*>(smem + G::l_hlo);
+    uint4* maskt = reinterpret_cast<uint4*>(smem + G::l_mask);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int H = args.H, W = args.W;
@@ -195,8 +223,8 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
     auto wmat = [&](int s, size_t off) { return reinterpret_cast<const bf16*>(wsec(s) + off); };
     auto wvec = [&](int s) { return reinterpret_cast<const float*>(wsec(s) + G::p_vec); };
 
-    // ---- once per workgroup: stage both streams' weights into LDS, clear the A / Q / K images
-    //      (their K padding must stay exact zeros: 0 * stale-NaN would poison a dot product) ----
+    // ---- once per workgroup: weights -> LDS, zero the images (the K padding of Q / K rows is never written
+    //      again and must read as exact zeros), build the per-head channel masks ----
     {
         constexpr int W16 = G::wsec / 16;
         for (int i = tid; i < 2 * W16; i += 512) {
@@ -206,91 +234,104 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         constexpr int Z16 = (G::l_vt - G::l_ahi) / 16;
         uint4* z = reinterpret_cast<uint4*>(smem + G::l_ahi);
         for (int i = tid; i < Z16; i += 512) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < G::HEADS * G::NKS * 2; i += 512) {
+            const int hf = i & 1, ks = (i >> 1) % G::NKS, head = i / (2 * G::NKS);
+            unsigned m[4];
+#pragma unroll
+            for (int dwd = 0; dwd < 4; ++dwd) {
+                const int ch = ks * 16 + hf * 8 + dwd * 2;
+                m[dwd] = ((ch >= head * D && ch < head * D + D) ? 0xFFFFu : 0u) | ((ch + 1 >= head * D && ch + 1 < head * D + D) ? 0xFFFF0000u : 0u);
+            }
+            maskt[i] = make_uint4(m[0], m[1], m[2], m[3]);
+        }
     }
 
-    // window tile <-> registers: 2*64*C/4 float4 over 512 threads
-    constexpr int V4 = T * C / 4, NV = cceil(2 * V4, 512);
-    float4 pre[NV];
+    // the wave's own 16 token rows <-> registers (C/4 float4 per token)
+    const int ws = wave >> 2, wm = wave & 3;           // stream and m-tile this wave owns
+    constexpr int V4 = 16 * C / 4, NV = cceil(V4, 64);
+    static_assert(NV <= 4, "prefetch registers");
+    float4 pre0, pre1, pre2, pre3;   // named registers: an array captured by a lambda is demoted to scratch
+    pre0 = pre1 = pre2 = pre3 = make_float4(0.f, 0.f, 0.f, 0.f);
     auto tile_addr = [&](int win, int i) -> int64_t {
         const int b = win / (nwx * nwy), wrem = win % (nwx * nwy);
         const int wy = wrem / nwx, wx = wrem % nwx;
-        const int e = i % V4;
-        const int tok = e / (C / 4), c4 = e % (C / 4);
+        const int tok = wm * 16 + i / (C / 4), c4 = i % (C / 4);
         const int oy = (wy * G::WH + tok / G::WW + sh) % H, ox = (wx * G::WW + tok % G::WW + sw) % W;   // roll(-s): read at (y+s)%H
         return (((int64_t)b * H + oy) * W + ox) * C + c4 * 4;
     };
-    auto prefetch = [&](int win) {
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int i = tid + k * 512;
-            if (i < 2 * V4) pre[k] = *reinterpret_cast<const float4*>(args.in[i / V4] + tile_addr(win, i));
-        }
-    };
+#define SWF_PREFETCH(WIN)                                                                                          \
+    do {                                                                                                           \
+        const float* src_ = args.in[ws];                                                                           \
+        if (lane < V4) pre0 = *reinterpret_cast<const float4*>(src_ + tile_addr((WIN), lane));                     \
+        if (NV > 1 && lane + 64 < V4) pre1 = *reinterpret_cast<const float4*>(src_ + tile_addr((WIN), lane + 64));   \
+        if (NV > 2 && lane + 128 < V4) pre2 = *reinterpret_cast<const float4*>(src_ + tile_addr((WIN), lane + 128)); \
+        if (NV > 3 && lane + 192 < V4) pre3 = *reinterpret_cast<const float4*>(src_ + tile_addr((WIN), lane + 192)); \
+    } while (0)
+    float* my_resid = resid + (ws * T + wm * 16) * C;
+    bf16* my_ahi = ahi + (ws * T + wm * 16) * LDC;
+    bf16* my_alo = alo + (ws * T + wm * 16) * LDC;
 
     int win = blockIdx.x;
-    if (win < nwin) prefetch(win);
+    if (win < nwin) SWF_PREFETCH(win);
     int cur_variant = -1;
     f32x16 bfr[2];   // relative-position bias (+mask) of this wave's (stream, query block), S^T layout, exp2 units
     __syncthreads();
 
+    const int r16 = lane & 15, g = lane >> 4;
     for (; win < nwin; win += gridDim.x) {
         const int wrem = win % (nwx * nwy);
         const int wy = wrem / nwx, wx = wrem % nwx;
-        // ---- phase 0: registers -> residual tile; start fetching the next window ----
-#pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int i = tid + k * 512;
-            if (i < 2 * V4) {
-                const int e = i % V4;
-                *reinterpret_cast<float4*>(resid + ((i / V4) * T + e / (C / 4)) * C + (e % (C / 4)) * 4) = pre[k];
-            }
-        }
-        __syncthreads();
-        if (win + (int)gridDim.x < nwin) prefetch(win + gridDim.x);
+        // ---- own rows: registers -> residual; start fetching the next window ----
+        if (lane < V4) *reinterpret_cast<float4*>(my_resid + lane * 4) = pre0;
+        if (NV > 1 && lane + 64 < V4) *reinterpret_cast<float4*>(my_resid + (lane + 64) * 4) = pre1;
+        if (NV > 2 && lane + 128 < V4) *reinterpret_cast<float4*>(my_resid + (lane + 128) * 4) = pre2;
+        if (NV > 3 && lane + 192 < V4) *reinterpret_cast<float4*>(my_resid + (lane + 192) * 4) = pre3;
+        if (win + (int)gridDim.x < nwin) SWF_PREFETCH(win + gridDim.x);
 
-        // ---- phase 1: LN1 -> split-bf16 A image ----
-        layernorm_to_image<G>(resid, ahi, alo, wvec(0), wvec(1), G::v_ln1g, G::v_ln1b, tid);
-        __syncthreads();
+        // ---- LN1 -> A image (own rows) ----
+        if (!(args.dbg_skip & 1)) layernorm_rows<G>(my_resid, my_ahi, my_alo, wvec(ws), G::v_ln1g, G::v_ln1b, lane);
 
-        // ---- phase 2: Q, K, V projections.  flat job = ((stream, n-tile of [Q|K|V]), m-tile), m fastest,
-        //      each wave takes a contiguous run so a weight fragment is fetched once per n-tile ----
-        {
-            constexpr int NJ = 2 * 3 * G::NTC * 4, JPW = cceil(NJ, 8);
-            const int r = lane & 15, g = lane >> 4;
-            BFrag<G::KC / 32> bf;
-            int cur = -1;
-#pragma unroll 1
-            for (int jj = 0; jj < JPW; ++jj) {
-                const int job = wave * JPW + jj;
-                if (job >= NJ) break;
-                const int m = job & 3, sn = job >> 2;
-                const int s = sn / (3 * G::NTC), n = sn % (3 * G::NTC);
-                const int which = n / G::NTC, nt = n % G::NTC;
-                const int ch = nt * 16 + r;
-                if (sn != cur) {
-                    cur = sn;
-                    load_bfrag<G::KC / 32, G::KC>(bf, wmat(s, G::p_wqkv_hi), wmat(s, G::p_wqkv_lo), which * C + (ch < C ? ch : 0), g);
-                }
-                const int src = (which != 0 && args.cross) ? 1 - s : s;   // cross: K,V come from the other stream (a002:67-82)
-                const f32x4 acc = tile_bf16x3<G::KC / 32, G::LDC>(ahi + (src * T + m * 16) * G::LDC, alo + (src * T + m * 16) * G::LDC, bf, r, g);
-                if (ch < C) {
-                    const float bias = wvec(s)[G::v_bqkv + which * C + ch];
-                    const int head = ch / D, c = ch % D;
+        // ---- Q, K, V projections of the own rows.  Q for the own stream; K and V for the stream whose attention
+        //      reads these tokens as keys: itself, or the other one in a cross block (a002:67-82) ----
+        if (!(args.dbg_skip & 2)) {
+            Frag<KS> x;
+            load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
+            const int kvs = args.cross ? 1 - ws : ws;
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const int tok = m * 16 + 4 * g + j;
-                        const float v = acc[j] + bias;
-                        if (which == 0) qimg[((s * G::HEADS + head) * T + tok) * QS + c] = (bf16)v;
-                        else if (which == 1) kimg[((s * G::HEADS + head) * T + tok) * QS + c] = (bf16)v;
-                        else vt[((s * G::HEADS + head) * D + c) * T + vt_pos(tok)] = (f16)v;
+            for (int nt = 0; nt < G::NTC; ++nt) {
+                const int ch4 = nt * 16 + 4 * g;           // this lane's 4 output channels (transposed tiles)
+                const int wrow = nt * 16 + r16 < C ? nt * 16 + r16 : 0;
+                Frag<KS> wq, wk, wv;
+                load_frag<KS, G::KC>(wq, wmat(ws, G::p_wqkv_hi), wmat(ws, G::p_wqkv_lo), wrow, g);
+                load_frag<KS, G::KC>(wk, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), C + wrow, g);
+                load_frag<KS, G::KC>(wv, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), 2 * C + wrow, g);
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 aq = mma_bf16x3<KS>(wq, x, z4);   // [channel 4g+j][token r16]
+                const f32x4 ak = mma_bf16x3<KS>(wk, x, z4);
+                const f32x4 av = mma_bf16x3<KS>(x, wv, z4);   // [token 4g+j][channel r16]
+                if (ch4 < G::KC) {   // columns C..KC-1 are the K padding: rewritten as zeros (the MLP's hidden chunks reuse these rows)
+                    bf16x4 q4 = {0, 0, 0, 0}, k4 = {0, 0, 0, 0};
+                    if (ch4 < C) {
+                        const float4 bq = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bqkv + ch4);
+                        const float4 bk = *reinterpret_cast<const float4*>(wvec(kvs) + G::v_bqkv + C + ch4);
+                        q4 = bf16x4{(bf16)(aq[0] + bq.x), (bf16)(aq[1] + bq.y), (bf16)(aq[2] + bq.z), (bf16)(aq[3] + bq.w)};
+                        k4 = bf16x4{(bf16)(ak[0] + bk.x), (bf16)(ak[1] + bk.y), (bf16)(ak[2] + bk.z), (bf16)(ak[3] + bk.w)};
                     }
+                    *reinterpret_cast<bf16x4*>(qimg + (ws * T + wm * 16 + r16) * LDC + ch4) = q4;
+                    *reinterpret_cast<bf16x4*>(kimg + (kvs * T + wm * 16 + r16) * LDC + ch4) = k4;
+                }
+                const int chv = nt * 16 + r16;
+                if (chv < C) {
+                    const float bv = wvec(kvs)[G::v_bqkv + 2 * C + chv];
+                    f16x4 v4 = {(f16)(av[0] + bv), (f16)(av[1] + bv), (f16)(av[2] + bv), (f16)(av[3] + bv)};
+                    *reinterpret_cast<f16x4*>(vt + (kvs * C + chv) * G::VRS + vt_pos(wm * 16 + 4 * g)) = v4;
                 }
             }
         }
-        __syncthreads();
+        __syncthreads();   // all Q / K / V^T rows of the window are in place
 
-        // ---- phase 3: attention.  wave -> (stream, 32-query block, 4 heads) ----
-        {
+        // ---- attention.  wave -> (stream, 32-query block, 4 heads) ----
+        if (!(args.dbg_skip & 4)) {
             const int s = wave >> 2, qb = (wave >> 1) & 1, h0 = (wave & 1) * 4;
             const int r = lane & 31, hf = lane >> 5;
             const int variant = args.shift ? ((wy == nwy - 1) * 2 + (wx == nwx - 1)) : 0;
@@ -302,42 +343,55 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
 #pragma unroll
                     for (int i = 0; i < 16; ++i) bfr[kt][i] = bias4[(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hf) * T + 32 * qb + r];
             }
-            const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+            const bf16* qrow = qimg + (s * T + 32 * qb + r) * LDC + 8 * hf;
+            const bf16* krow0 = kimg + (s * T + r) * LDC + 8 * hf;
+            const bf16* krow1 = krow0 + 32 * LDC;
+            f16x8 ones8;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ones8[e] = (f16)1.0f;
+#pragma unroll 2
             for (int hh = 0; hh < 4; ++hh) {
                 const int head = h0 + hh;
-                const bf16* qrow = qimg + ((s * G::HEADS + head) * T + 32 * qb + r) * QS;
-                f32x16 acc[2];
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt) {
-                    acc[kt] = bfr[kt];
-                    const bf16* krow = kimg + ((s * G::HEADS + head) * T + 32 * kt + r) * QS;
-#pragma unroll
-                    for (int ks = 0; ks < G::QKS; ++ks) {
-                        // lane half hf supplies k = 16*ks + 8*hf .. +7; slots beyond the stored row width are zeros
-                        bf16x8 ka = zero8, qv = zero8;
-                        if (ks * 16 + 8 * hf + 8 <= QS) {
-                            ka = *reinterpret_cast<const bf16x8*>(krow + ks * 16 + 8 * hf);
-                            qv = *reinterpret_cast<const bf16x8*>(qrow + ks * 16 + 8 * hf);
-                        }
-                        acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qv, acc[kt], 0, 0, 0);
-                    }
+                // S^T = K . Qmasked^T: K rows carry all channels, the Q fragment is ANDed with the head's channel mask,
+                // so only the 16-deep k-steps that the head's channels touch are issued (1 or 2 for D <= 16).  The
+                // bias (+mask) registers are the C operand of the first step: no accumulator copy.
+                const int ks_lo = (head * D) >> 4, ks_hi = (head * D + D - 1) >> 4;
+                f32x16 acc0, acc1;
+                {
+                    const uint4 mk = maskt[(head * G::NKS + ks_lo) * 2 + hf];
+                    uint4 qv = *reinterpret_cast<const uint4*>(qrow + ks_lo * 16);
+                    qv.x &= mk.x; qv.y &= mk.y; qv.z &= mk.z; qv.w &= mk.w;
+                    const bf16x8 qf = __builtin_bit_cast(bf16x8, qv);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow0 + ks_lo * 16), qf, bfr[0], 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow1 + ks_lo * 16), qf, bfr[1], 0, 0, 0);
                 }
-                float mx = acc[0][0];
+                for (int ks = ks_lo + 1; ks <= ks_hi; ++ks) {
+                    const uint4 mk = maskt[(head * G::NKS + ks) * 2 + hf];
+                    uint4 qv = *reinterpret_cast<const uint4*>(qrow + ks * 16);
+                    qv.x &= mk.x; qv.y &= mk.y; qv.z &= mk.z; qv.w &= mk.w;
+                    const bf16x8 qf = __builtin_bit_cast(bf16x8, qv);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow0 + ks * 16), qf, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow1 + ks * 16), qf, acc1, 0, 0, 0);
+                }
+                // row max over the lane's 32 keys with v_max3 (hipcc would emit canonicalising v_max pairs), then
+                // across the two lane halves
+                float mx = max3f(acc0[0], acc0[1], acc1[0]);
+                mx = max3f(mx, acc1[1], acc0[2]);
 #pragma unroll
-                for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[0][i]);
+                for (int i = 3; i < 16; i += 2) mx = max3f(mx, acc0[i], acc0[i + 1 < 16 ? i + 1 : i]);
 #pragma unroll
-                for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc[1][i]);
+                for (int i = 2; i < 16; i += 2) mx = max3f(mx, acc1[i], acc1[i + 1]);
                 mx = fmaxf(mx, __shfl_xor(mx, 32));
-                float l = 0.f;
+                const f32x2 m2 = {mx, mx};
 #pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const float p = __builtin_amdgcn_exp2f(acc[kt][i] - mx);
-                        acc[kt][i] = p;
-                        l += p;
-                    }
-                l += __shfl_xor(l, 32);
+                for (int i = 0; i < 16; i += 2) {
+                    f32x2 a = {acc0[i], acc0[i + 1]}, b = {acc1[i], acc1[i + 1]};
+                    a -= m2; b -= m2;
+                    acc0[i] = __builtin_amdgcn_exp2f(a[0]); acc0[i + 1] = __builtin_amdgcn_exp2f(a[1]);
+                    acc1[i] = __builtin_amdgcn_exp2f(b[0]); acc1[i + 1] = __builtin_amdgcn_exp2f(b[1]);
+                }
+                // O^T = V^T . P^T; row D of the V^T operand is all ones, so row D of the result is the softmax
+                // denominator, summed by the MFMA from the same fp16-rounded P that feeds the numerator
                 f32x16 o[G::MT];
 #pragma unroll
                 for (int mt = 0; mt < G::MT; ++mt)
@@ -349,15 +403,20 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                     for (int s2 = 0; s2 < 2; ++s2) {
                         f16x8 pf;
 #pragma unroll
-                        for (int e = 0; e < 8; ++e) pf[e] = (f16)acc[kt][8 * s2 + e];
+                        for (int e = 0; e < 8; ++e) pf[e] = (f16)(kt == 0 ? acc0[8 * s2 + e] : acc1[8 * s2 + e]);
 #pragma unroll
                         for (int mt = 0; mt < G::MT; ++mt) {
-                            int c = mt * 32 + r;
-                            c = c < D ? c : D - 1;   // rows beyond the head width are never read back
-                            const f16x8 va = *reinterpret_cast<const f16x8*>(vt + ((s * G::HEADS + head) * D + c) * T + kt * 32 + s2 * 16 + 8 * hf);
+                            const int c = mt * 32 + r;
+                            f16x8 va = *reinterpret_cast<const f16x8*>(vt + (s * C + head * D + (c < D ? c : D - 1)) * G::VRS + kt * 32 + s2 * 16 + 8 * hf);
+                            if (c == D) va = ones8;
                             o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pf, o[mt], 0, 0, 0);
                         }
                     }
+                // the denominator sits in tile D/32, register (D&3) + 4*((D&31)>>3), lane half (D>>2)&1
+                constexpr int LM = D / 32, LI = (D & 3) + 4 * ((D & 31) >> 3), LH = (D >> 2) & 1;
+                float l = o[LM][LI];
+                const float l_other = __shfl_xor(l, 32);
+                l = (hf == LH) ? l : l_other;
                 const float inv = 1.0f / l;
                 const int tok = 32 * qb + r;
 #pragma unroll
@@ -366,133 +425,272 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                     for (int i = 0; i < 16; ++i) {
                         const int c = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
                         if (c < D) {
-                            bf16 hi, lo;
-                            split_bf16(o[mt][i] * inv, hi, lo);
-                            ahi[(s * T + tok) * G::LDC + head * D + c] = hi;   // xn is dead: the A image now carries O
-                            alo[(s * T + tok) * G::LDC + head * D + c] = lo;
+                            const float ov = o[mt][i] * inv;
+                            const bf16 hi = (bf16)ov;
+                            ahi[(s * T + tok) * LDC + head * D + c] = hi;   // xn is dead: the A image now carries O
+                            alo[(s * T + tok) * LDC + head * D + c] = (bf16)(ov - (float)hi);
                         }
                     }
             }
         }
-        __syncthreads();
+        __syncthreads();   // O rows complete
 
-        // ---- phase 4: output projection + residual ----
-        {
-            constexpr int NJ = 2 * G::NTC * 4, JPW = cceil(NJ, 8);
-            const int r = lane & 15, g = lane >> 4;
-            BFrag<G::KC / 32> bf;
-            int cur = -1;
-#pragma unroll 1
-            for (int jj = 0; jj < JPW; ++jj) {
-                const int job = wave * JPW + jj;
-                if (job >= NJ) break;
-                const int m = job & 3, sn = job >> 2;
-                const int s = sn / G::NTC, nt = sn % G::NTC;
-                const int ch = nt * 16 + r;
-                if (sn != cur) {
-                    cur = sn;
-                    load_bfrag<G::KC / 32, G::KC>(bf, wmat(s, G::p_wp_hi), wmat(s, G::p_wp_lo), ch < C ? ch : 0, g);
-                }
-                const f32x4 acc = tile_bf16x3<G::KC / 32, G::LDC>(ahi + (s * T + m * 16) * G::LDC, alo + (s * T + m * 16) * G::LDC, bf, r, g);
-                if (ch < C) {
-                    const float bias = wvec(s)[G::v_bp + ch];
+        // ---- output projection + residual (own rows; transposed tiles: a lane holds 4 channels of one token) ----
+        if (!(args.dbg_skip & 8)) {
+            Frag<KS> x;
+            load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) resid[(s * T + m * 16 + 4 * g + j) * C + ch] += acc[j] + bias;
+            for (int nt = 0; nt < G::NTC; ++nt) {
+                const int ch4 = nt * 16 + 4 * g;
+                Frag<KS> wp;
+                load_frag<KS, G::KC>(wp, wmat(ws, G::p_wp_hi), wmat(ws, G::p_wp_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g);
+                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                const f32x4 acc = mma_bf16x3<KS>(wp, x, z4);
+                if (ch4 < C) {
+                    const float4 bp = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bp + ch4);
+                    float4* rp = reinterpret_cast<float4*>(my_resid + r16 * C + ch4);
+                    float4 rv = *rp;
+                    rv.x += acc[0] + bp.x; rv.y += acc[1] + bp.y; rv.z += acc[2] + bp.z; rv.w += acc[3] + bp.w;
+                    *rp = rv;
                 }
             }
         }
-        __syncthreads();
 
-        // ---- phase 5: LN2 (the hidden image's K padding, which overlays the attention images, is re-zeroed) ----
-        layernorm_to_image<G>(resid, ahi, alo, wvec(0), wvec(1), G::v_ln2g, G::v_ln2b, tid);
-        if constexpr (G::KH > G::NH) {
-            constexpr int PADW = G::KH - G::NH;
-            for (int i = tid; i < 2 * T * PADW; i += 512) {
-                const int row = i / PADW, c = G::NH + i % PADW;
-                hhi[row * G::LDH + c] = (bf16)0.f;
-                hlo[row * G::LDH + c] = (bf16)0.f;
-            }
-        }
-        __syncthreads();
+        // ---- LN2 -> A image (own rows) ----
+        if (!(args.dbg_skip & 16)) layernorm_rows<G>(my_resid, my_ahi, my_alo, wvec(ws), G::v_ln2g, G::v_ln2b, lane);
 
-        // ---- phase 6: MLP fc1 + ELU -> split-bf16 hidden image ----
-        {
-            constexpr int NJ = 2 * G::NTH * 4, JPW = cceil(NJ, 8);
-            const int r = lane & 15, g = lane >> 4;
-            BFrag<G::KC / 32> bf;
-            int cur = -1;
-#pragma unroll 1
-            for (int jj = 0; jj < JPW; ++jj) {
-                const int job = wave * JPW + jj;
-                if (job >= NJ) break;
-                const int m = job & 3, sn = job >> 2;
-                const int s = sn / G::NTH, nt = sn % G::NTH;
-                const int ch = nt * 16 + r;
-                if (sn != cur) {
-                    cur = sn;
-                    load_bfrag<G::KC / 32, G::KC>(bf, wmat(s, G::p_w1_hi), wmat(s, G::p_w1_lo), ch < G::HID ? ch : 0, g);
-                }
-                const f32x4 acc = tile_bf16x3<G::KC / 32, G::LDC>(ahi + (s * T + m * 16) * G::LDC, alo + (s * T + m * 16) * G::LDC, bf, r, g);
-                const float bias = wvec(s)[G::v_b1 + ch];   // zero-padded to NH
+        // ---- MLP, own rows, walking the hidden dimension in chunks of 32: fc1 + ELU for the chunk -> split-bf16
+        //      image over the wave's own A rows (xn2 already sits in registers) -> one k-step of fc2.  The hidden
+        //      activations never exist as a whole. ----
+        if (!(args.dbg_skip & 32)) {
+            Frag<KS> x;
+            load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
+            f32x4 out[G::NTC];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const float v = ch < G::HID ? elu_f(acc[j] + bias) : 0.f;
-                    bf16 hi, lo;
-                    split_bf16(v, hi, lo);
-                    hhi[(s * T + m * 16 + 4 * g + j) * G::LDH + ch] = hi;
-                    hlo[(s * T + m * 16 + 4 * g + j) * G::LDH + ch] = lo;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 7: MLP fc2 + residual ----
-        {
-            constexpr int NJ = 2 * G::NTC * 4, JPW = cceil(NJ, 8);
-            const int r = lane & 15, g = lane >> 4;
-            BFrag<G::KH / 32> bf;
-            int cur = -1;
-#pragma unroll 1
-            for (int jj = 0; jj < JPW; ++jj) {
-                const int job = wave * JPW + jj;
-                if (job >= NJ) break;
-                const int m = job & 3, sn = job >> 2;
-                const int s = sn / G::NTC, nt = sn % G::NTC;
-                const int ch = nt * 16 + r;
-                if (sn != cur) {
-                    cur = sn;
-                    load_bfrag<G::KH / 32, G::KH>(bf, wmat(s, G::p_w2_hi), wmat(s, G::p_w2_lo), ch < C ? ch : 0, g);
-                }
-                const f32x4 acc = tile_bf16x3<G::KH / 32, G::LDH>(hhi + (s * T + m * 16) * G::LDH, hlo + (s * T + m * 16) * G::LDH, bf, r, g);
-                if (ch < C) {
-                    const float bias = wvec(s)[G::v_b2 + ch];
+            for (int nt = 0; nt < G::NTC; ++nt) out[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            // two chunk buffers so consecutive chunks do not serialise on one LDS region: the wave's A rows, and
+            // the Q / K rows it wrote for this window (dead since the post-attention barrier; the projections of
+            // the next window rewrite them, K padding included)
+            bf16* hb_hi[2] = {my_ahi, qimg + (ws * T + wm * 16) * LDC};
+            bf16* hb_lo[2] = {my_alo, kimg + ((args.cross ? 1 - ws : ws) * T + wm * 16) * LDC};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j) resid[(s * T + m * 16 + 4 * g + j) * C + ch] += acc[j] + bias;
-                }
-            }
-        }
-        __syncthreads();
-
-        // ---- phase 8: store both tiles (un-shift = same index map as the load); clear the Q/K image
-        //      region again: the hidden image overlaid it and its K padding must read as zeros ----
-        {
+            for (int hc = 0; hc < G::KH / 32; ++hc) {
+                bf16* hhi = hb_hi[hc & 1];
+                bf16* hlo = hb_lo[hc & 1];
 #pragma unroll
-            for (int k = 0; k < NV; ++k) {
-                const int i = tid + k * 512;
-                if (i < 2 * V4) {
-                    const int e = i % V4;
-                    *reinterpret_cast<float4*>(args.out[i / V4] + tile_addr(win, i)) =
-                        *reinterpret_cast<const float4*>(resid + ((i / V4) * T + e / (C / 4)) * C + (e % (C / 4)) * 4);
+                for (int t2 = 0; t2 < 2; ++t2) {
+                    const int hid0 = hc * 32 + t2 * 16;
+                    bf16x4 h4 = {0, 0, 0, 0}, l4 = {0, 0, 0, 0};
+                    if (hid0 < G::HID) {   // compile-time: tiles wholly in the K padding are just zeros
+                        Frag<KS> w1;
+                        load_frag<KS, G::KC>(w1, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hid0 + r16 < G::HID ? hid0 + r16 : 0, g);
+                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                        const f32x4 acc = mma_bf16x3<KS>(w1, x, z4);   // [hidden 4g+j][token r16]
+                        const float4 b1 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hid0 + 4 * g);
+                        float v[4] = {acc[0] + b1.x, acc[1] + b1.y, acc[2] + b1.z, acc[3] + b1.w};
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) v[j] = (hid0 + 4 * g + j < G::HID) ? elu_fast(v[j]) : 0.f;
+                        split4_bf16(v, h4, l4);
+                    }
+                    *reinterpret_cast<bf16x4*>(hhi + r16 * LDC + t2 * 16 + 4 * g) = h4;
+                    *reinterpret_cast<bf16x4*>(hlo + r16 * LDC + t2 * 16 + 4 * g) = l4;
+                }
+                Frag<1> hfrag;
+                load_frag<1, LDC>(hfrag, hhi, hlo, r16, g);
+#pragma unroll
+                for (int nt = 0; nt < G::NTC; ++nt) {
+                    Frag<1> w2;
+                    load_frag<1, G::KH>(w2, wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
+                    out[nt] = mma_bf16x3<1>(w2, hfrag, out[nt]);
                 }
             }
-            if constexpr (QS != D) {
-                constexpr int Z16 = (G::l_vt - G::l_q) / 16;
-                uint4* z = reinterpret_cast<uint4*>(smem + G::l_q);
-                for (int i = tid; i < Z16; i += 512) z[i] = make_uint4(0, 0, 0, 0);
+#pragma unroll
+            for (int nt = 0; nt < G::NTC; ++nt) {
+                const int ch4 = nt * 16 + 4 * g;
+                if (ch4 < C) {
+                    const float4 b2 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b2 + ch4);
+                    float4* rp = reinterpret_cast<float4*>(my_resid + r16 * C + ch4);
+                    float4 rv = *rp;
+                    rv.x += out[nt][0] + b2.x; rv.y += out[nt][1] + b2.y; rv.z += out[nt][2] + b2.z; rv.w += out[nt][3] + b2.w;
+                    *rp = rv;
+                }
             }
         }
-        __syncthreads();
+
+        // ---- store the own rows (un-shift = same index map as the load) ----
+#pragma unroll
+        for (int k = 0; k < NV; ++k) {
+            const int i = lane + k * 64;
+            if (i < V4) *reinterpret_cast<float4*>(args.out[ws] + tile_addr(win, i)) = *reinterpret_cast<const float4*>(my_resid + i * 4);
+        }
     }
+#undef SWF_PREFETCH
+}
+
+// ------------------------------------------------------------------------------------------
+// Stand-alone MFMA attention core for 8x8 windows (levels whose linears run as separate GEMMs):
+// one workgroup = (window, group of 4 heads, stream), one wave per head.  Same arithmetic as phase 3 of
+// the block kernel; Q/K/V come from the fp32 projection buffers in global memory (token-major, image
+// order; the cyclic shift is index arithmetic), the bias (+mask) matrix is built per window in LDS.
+// ------------------------------------------------------------------------------------------
+struct AttnMfmaArgs {
+    const float* Q[2]; const float* K[2]; const float* V[2]; float* O[2]; const float* table[2];
+    int ldq, ldk, ldv, ldo, B, H, W, heads, shift;
+};
+
+template <int D>
+__global__ __launch_bounds__(256) void attn_core_mfma_kernel(AttnMfmaArgs a) {
+    constexpr int T = 64, WH = 8, WW = 8, HG = 4, QS = cround(D, 8), QKS = cceil(D, 16), MT = cceil(D, 32), TW = 2 * WW - 1;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    bf16* qimg = reinterpret_cast<bf16*>(smem);                 // [HG][64][QS]
+    bf16* kimg = qimg + HG * T * QS;
+    f16* vt = reinterpret_cast<f16*>(kimg + HG * T * QS);       // [HG][D][64]
+    float* biasm = reinterpret_cast<float*>(vt + HG * D * T);   // [64 keys][64 queries], exp2 units
+    float* tab = biasm + T * T;
+
+    const int p = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = a.H, W = a.W, nwx = W / WW, nwy = H / WH;
+    const int win = blockIdx.x, hg = blockIdx.y;
+    const int b = win / (nwx * nwy), wrem = win % (nwx * nwy), wy = wrem / nwx, wx = wrem % nwx;
+    const int sh = a.shift ? WH / 2 : 0, sw = a.shift ? WW / 2 : 0;
+    const float qscale = kLog2e / sqrtf((float)D);
+
+    for (int i = tid; i < (2 * WH - 1) * TW; i += 256) tab[i] = a.table[p][i];
+    // Q / K / V of this head group -> LDS images
+    for (int e = tid; e < T * HG * QS; e += 256) {
+        const int c = e % QS, hl = (e / QS) % HG, tok = e / (QS * HG);
+        const int head = hg * HG + hl;
+        float qv = 0.f, kv = 0.f;
+        if (c < D && head < a.heads) {
+            const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
+            const int64_t t = ((int64_t)b * H + oy) * W + ox;
+            qv = a.Q[p][t * a.ldq + head * D + c] * qscale;
+            kv = a.K[p][t * a.ldk + head * D + c];
+            vt[(hl * D + c) * T + vt_pos(tok)] = (f16)a.V[p][t * a.ldv + head * D + c];
+        }
+        qimg[(hl * T + tok) * QS + c] = (bf16)qv;
+        kimg[(hl * T + tok) * QS + c] = (bf16)kv;
+    }
+    __syncthreads();   // table visible
+    const bool last_row = a.shift && wy == nwy - 1, last_col = a.shift && wx == nwx - 1;
+    for (int i = tid; i < T * T; i += 256) {
+        const int key = i / T, q = i % T;
+        const int ky = key / WW, kx = key % WW, qy = q / WW, qx = q % WW;
+        float v = tab[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
+        const bool my = last_row && ((ky >= WH - WH / 2) != (qy >= WH - WH / 2));
+        const bool mx = last_col && ((kx >= WW - WW / 2) != (qx >= WW - WW / 2));
+        if (my || mx) v = -1e10f;
+        biasm[i] = v * kLog2e;
+    }
+    __syncthreads();
+
+    const int hl = wave, head = hg * HG + hl;
+    if (head >= a.heads) return;
+    const int r = lane & 31, hf = lane >> 5;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int qb = 0; qb < 2; ++qb) {
+        const bf16* qrow = qimg + (hl * T + 32 * qb + r) * QS;
+        f32x16 acc[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[kt][i] = biasm[(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hf) * T + 32 * qb + r];
+            const bf16* krow = kimg + (hl * T + 32 * kt + r) * QS;
+#pragma unroll
+            for (int ks = 0; ks < QKS; ++ks) {
+                bf16x8 ka = zero8, qv = zero8;
+                if (ks * 16 + 8 * hf + 8 <= QS) {
+                    ka = *reinterpret_cast<const bf16x8*>(krow + ks * 16 + 8 * hf);
+                    qv = *reinterpret_cast<const bf16x8*>(qrow + ks * 16 + 8 * hf);
+                }
+                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qv, acc[kt], 0, 0, 0);
+            }
+        }
+        float mx = acc[0][0];
+#pragma unroll
+        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[0][i]);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc[1][i]);
+        mx = fmaxf(mx, __shfl_xor(mx, 32));
+        float l = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const float pv = __builtin_amdgcn_exp2f(acc[kt][i] - mx);
+                acc[kt][i] = pv;
+                l += pv;
+            }
+        l += __shfl_xor(l, 32);
+        f32x16 o[MT];
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[mt][i] = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                f16x8 pf;
+#pragma unroll
+                for (int e = 0; e < 8; ++e) pf[e] = (f16)acc[kt][8 * s2 + e];
+#pragma unroll
+                for (int mt = 0; mt < MT; ++mt) {
+                    int c = mt * 32 + r;
+                    c = c < D ? c : D - 1;
+                    const f16x8 va = *reinterpret_cast<const f16x8*>(vt + (hl * D + c) * T + kt * 32 + s2 * 16 + 8 * hf);
+                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pf, o[mt], 0, 0, 0);
+                }
+            }
+        const float inv = 1.0f / l;
+        const int tok = 32 * qb + r;
+        const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
+        float* orow = a.O[p] + (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                const int c = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
+                if (c < D) orow[c] = o[mt][i] * inv;
+            }
+    }
+}
+
+template <int D>
+static int launch_attn_mfma_t(const AttnMfmaArgs& a, int nprob, hipStream_t stream) {
+    constexpr int QS = cround(D, 8);
+    constexpr size_t lds = size_t(2) * 4 * 64 * QS * 2 + size_t(4) * D * 64 * 2 + 64 * 64 * 4 + 15 * 15 * 4;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    if (lds > 64 * 1024)
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_mfma_kernel<D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+    if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(attn_core_mfma): %s", hipGetErrorString(attr_err));
+    const int nwin = a.B * (a.H / 8) * (a.W / 8);
+    hipLaunchKernelGGL((attn_core_mfma_kernel<D>), dim3(nwin, cceil(a.heads, 4), nprob), dim3(256), lds, stream, a);
+    return check_launch("attn_core_mfma");
+}
+
+bool attn_core_mfma_supported(int wh, int ww, int head_dim) {
+    return wh == 8 && ww == 8 && (head_dim == 3 || head_dim == 6 || head_dim == 12 || head_dim == 24 || head_dim == 48);
+}
+
+int launch_attn_core_mfma(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
+                          const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
+                          int heads, int head_dim, int shift, hipStream_t stream) {
+    AttnMfmaArgs a{};
+    for (int i = 0; i < nprob; ++i) { a.Q[i] = Q[i]; a.K[i] = K[i]; a.V[i] = V[i]; a.O[i] = O[i]; a.table[i] = table[i]; }
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.W = W; a.heads = heads; a.shift = shift;
+    switch (head_dim) {
+        case 3: return launch_attn_mfma_t<3>(a, nprob, stream);
+        case 6: return launch_attn_mfma_t<6>(a, nprob, stream);
+        case 12: return launch_attn_mfma_t<12>(a, nprob, stream);
+        case 24: return launch_attn_mfma_t<24>(a, nprob, stream);
+        case 48: return launch_attn_mfma_t<48>(a, nprob, stream);
+    }
+    return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: head_dim %d", head_dim);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -518,11 +716,11 @@ __global__ __launch_bounds__(256) void pack_block_kernel(PackArgs a) {
     const swf_linear* qkv[3] = {&p.attn.q, &p.attn.k, &p.attn.v};
     for (int i = gtid; i < G::v_end; i += gsz) {
         float v = 0.f;
-        if (i < G::v_ln1b) v = p.ln1.gamma[i - G::v_ln1g];
-        else if (i < G::v_ln2g) v = p.ln1.beta[i - G::v_ln1b];
-        else if (i < G::v_ln2b) v = p.ln2.gamma[i - G::v_ln2g];
-        else if (i < G::v_bqkv) v = p.ln2.beta[i - G::v_ln2b];
-        else if (i < G::v_bp) {
+        if (i < G::v_bqkv) {   // LayerNorm gamma / beta, each padded to KC with zeros
+            const int which = i / G::KC, c = i % G::KC;
+            const float* src = which == 0 ? p.ln1.gamma : which == 1 ? p.ln1.beta : which == 2 ? p.ln2.gamma : p.ln2.beta;
+            v = c < C ? src[c] : 0.f;
+        } else if (i < G::v_bp) {
             const int which = (i - G::v_bqkv) / C, n = (i - G::v_bqkv) % C;
             v = qkv[which]->bias ? qkv[which]->bias[n] : 0.f;
             if (which == 0) v *= qscale;
@@ -647,6 +845,7 @@ int launch_window_block(const swf_block_desc& d, const void* packed_x, const voi
     a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
     a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
+    a.dbg_skip = getenv("SWF_DEBUG_SKIP") ? atoi(getenv("SWF_DEBUG_SKIP")) : 0;
     const int nwin = B * (H / 8) * (W / 8);
 #define X(C, HID) if (dims_match(d, C, HID)) return launch_t<C, HID>(a, nwin, stream);
     SWF_WINDOW_SHAPES(X)

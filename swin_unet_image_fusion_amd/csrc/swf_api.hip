@@ -39,11 +39,11 @@ static int check_attn_desc(const swf_attn_desc* d, int B, int H, int W) {
 static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn_params* const* prm,
                              const float* const* qsrc, const float* const* ksrc, const float* const* vsrc,
                              const float* const* residual, float* const* out, int B, int H, int W, Carver& ws,
-                             hipStream_t stream) {
+                             hipStream_t stream, int fast = 0) {
     const int64_t N = (int64_t)B * H * W;
     const int C = d.channels, HD = d.heads * d.head_dim;
-    float* qkv[2][3];
-    float* o[2];
+    float* qkv[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
+    float* o[2] = {nullptr, nullptr};
     for (int s = 0; s < nstream; ++s) {
         for (int i = 0; i < 3; ++i) qkv[s][i] = ws.floats(N * HD);
         o[s] = ws.floats(N * HD);
@@ -55,14 +55,22 @@ static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn
         const float* src[3] = {qsrc[s], ksrc[s], vsrc[s]};
         for (int i = 0; i < 3; ++i) gb.p[s * 3 + i] = GemmProb{src[i], lin[i]->weight, lin[i]->bias, nullptr, qkv[s][i]};
     }
-    SWF_TRY(launch_gemm_f32(gb, nstream * 3, (int)N, HD, C, C, HD, 0, stream));
-    AttnCoreBatch ab{};
-    for (int s = 0; s < nstream; ++s) ab.p[s] = AttnCoreProb{qkv[s][0], qkv[s][1], qkv[s][2], o[s], prm[s]->bias_table};
-    SWF_TRY(launch_attn_core(ab, nstream, HD, HD, HD, HD, B, H, W, d.win_h, d.win_w, d.heads, d.head_dim, d.shift, stream));
+    SWF_TRY(launch_gemm(fast, gb, nstream * 3, (int)N, HD, C, C, HD, 0, stream));
+    if (fast && attn_core_mfma_supported(d.win_h, d.win_w, d.head_dim)) {
+        const float* qq[2] = {qkv[0][0], qkv[1][0]};
+        const float* kk[2] = {qkv[0][1], qkv[1][1]};
+        const float* vv[2] = {qkv[0][2], qkv[1][2]};
+        const float* tt[2] = {prm[0]->bias_table, nstream == 2 ? prm[1]->bias_table : nullptr};
+        SWF_TRY(launch_attn_core_mfma(qq, kk, vv, o, tt, nstream, HD, HD, HD, HD, B, H, W, d.heads, d.head_dim, d.shift, stream));
+    } else {
+        AttnCoreBatch ab{};
+        for (int s = 0; s < nstream; ++s) ab.p[s] = AttnCoreProb{qkv[s][0], qkv[s][1], qkv[s][2], o[s], prm[s]->bias_table};
+        SWF_TRY(launch_attn_core(ab, nstream, HD, HD, HD, HD, B, H, W, d.win_h, d.win_w, d.heads, d.head_dim, d.shift, stream));
+    }
     GemmBatch pb{};
     for (int s = 0; s < nstream; ++s)
         pb.p[s] = GemmProb{o[s], prm[s]->proj.weight, prm[s]->proj.bias, residual ? residual[s] : nullptr, out[s]};
-    SWF_TRY(launch_gemm_f32(pb, nstream, (int)N, C, HD, HD, C, 0, stream));
+    SWF_TRY(launch_gemm(fast, pb, nstream, (int)N, C, HD, HD, C, 0, stream));
     return SWF_OK;
 }
 
@@ -101,7 +109,7 @@ static int attn_halfblock_generic(const swf_block_desc* desc, const swf_block_st
     const float* kvsrc[2] = {cross ? xn[1] : xn[0], cross ? xn[0] : xn[1]};
     const float* res[2] = {x_in, y_in};
     float* out[2] = {x_out, y_out};
-    return attention_generic(desc->attn, nstream, prm, qsrc, kvsrc, kvsrc, res, out, B, H, W, ws, stream);
+    return attention_generic(desc->attn, nstream, prm, qsrc, kvsrc, kvsrc, res, out, B, H, W, ws, stream, desc->precision == SWF_PREC_FAST);
 }
 
 static int mlp_halfblock_generic(const swf_block_desc* desc, const swf_block_stream_params* px,
@@ -125,8 +133,9 @@ static int mlp_halfblock_generic(const swf_block_desc* desc, const swf_block_str
         g1.p[s] = GemmProb{xn[s], pp[s]->fc1.weight, pp[s]->fc1.bias, nullptr, hb[s]};
         g2.p[s] = GemmProb{hb[s], pp[s]->fc2.weight, pp[s]->fc2.bias, res[s], out[s]};
     }
-    SWF_TRY(launch_gemm_f32(g1, nstream, (int)N, hid, C, C, hid, 1, stream));
-    SWF_TRY(launch_gemm_f32(g2, nstream, (int)N, C, hid, hid, C, 0, stream));
+    const int fast = desc->precision == SWF_PREC_FAST;
+    SWF_TRY(launch_gemm(fast, g1, nstream, (int)N, hid, C, C, hid, 1, stream));
+    SWF_TRY(launch_gemm(fast, g2, nstream, (int)N, C, hid, hid, C, 0, stream));
     return SWF_OK;
 }
 
@@ -195,7 +204,7 @@ static int merge_shapes(int H, int W, int mh, int mw, int wh, int ww, int* Hm, i
 
 static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const float* const* in, float* const* out,
                             int B, int H, int W, int Cin, int Cout, int mh, int mw, int wh, int ww, void* workspace,
-                            size_t workspace_bytes, hipStream_t stream) {
+                            size_t workspace_bytes, hipStream_t stream, int fast = 0) {
     int Hm, Wm, Ho, Wo;
     SWF_TRY(merge_shapes(H, W, mh, mw, wh, ww, &Hm, &Wm, &Ho, &Wo));
     const int64_t N = (int64_t)B * Ho * Wo;
@@ -214,14 +223,14 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
         lb.p[s] = LnProb{z[s], out[s], p[s]->ln.gamma, p[s]->ln.beta};
     }
     SWF_TRY(launch_merge_gather(pp, nstream, B, H, W, Cin, mh, mw, Hm, Wm, Ho, Wo, stream));
-    SWF_TRY(launch_gemm_f32(gb, nstream, (int)N, Cout, K, K, Cout, 0, stream));
+    SWF_TRY(launch_gemm(fast, gb, nstream, (int)N, Cout, K, K, Cout, 0, stream));
     return launch_layernorm(lb, nstream, N, Cout, 1, stream);
 }
 
 static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, const float* const* in,
                               const float* const* skip, float* const* out, int B, int Hp, int Wp, int Hm, int Wm, int Cin,
                               int Cout, int mh, int mw, int Hout, int Wout, void* workspace, size_t workspace_bytes,
-                              hipStream_t stream) {
+                              hipStream_t stream, int fast = 0) {
     if (Hm <= 0 || Wm <= 0 || Hm > Hp || Wm > Wp) return fail(SWF_ERR_BAD_SHAPE, "crop %dx%d of %dx%d", Hm, Wm, Hp, Wp);
     if (Hout <= 0 || Wout <= 0 || Hout > Hm * mh || Wout > Wm * mw)
         return fail(SWF_ERR_BAD_SHAPE, "output %dx%d larger than the unmerged map %dx%d", Hout, Wout, Hm * mh, Wm * mw);
@@ -248,7 +257,7 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
         sp.in[s] = zn[s]; sp.out[s] = out[s]; sp.aux[s] = skip ? skip[s] : nullptr;
     }
     if (need_crop) SWF_TRY(launch_crop(cp, nstream, B, Hp, Wp, Hm, Wm, Cin, stream));
-    SWF_TRY(launch_gemm_f32(gb, nstream, (int)N, Kz, Cin, Cin, Kz, 0, stream));
+    SWF_TRY(launch_gemm(fast, gb, nstream, (int)N, Kz, Cin, Cin, Kz, 0, stream));
     SWF_TRY(launch_layernorm(lb, nstream, N, Kz, 0, stream));
     return launch_unmerge_scatter(sp, nstream, B, Hm, Wm, Cout, mh, mw, Hout, Wout, stream);
 }
@@ -688,7 +697,7 @@ int swf_model_forward(const swf_model_desc* desc, const float* arena, const floa
         swf_patch_params pm[2] = {patch_params(L->enc_patch[s][0]), patch_params(L->enc_patch[s][1])};
         const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
         SWF_TRY(patch_merge_impl(pmp, 2, cur, act[s], B, ls[s].Hin, ls[s].Win, desc->in_dims[s], desc->out_dims[s], desc->merge_h,
-                                 desc->merge_w, desc->win_h, desc->win_w, scratch, scratch_bytes, stream));
+                                 desc->merge_w, desc->win_h, desc->win_w, scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST));
         swf_block_stream_params px[4], py[4];
         for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->enc_blk[s][i][0]); py[i] = make_stream_params(arena, L->enc_blk[s][i][1]); }
         swf_block_desc bd = level_block_desc(desc, s, true);
@@ -710,7 +719,7 @@ int swf_model_forward(const swf_model_desc* desc, const float* arena, const floa
         float* outs[2] = {lvl > 0 ? act[lvl - 1][0] : full[0], lvl > 0 ? act[lvl - 1][1] : full[1]};
         SWF_TRY(patch_unmerge_impl(pmp, 2, ins, lvl > 0 ? skip : nullptr, outs, B, ls[lvl].Ho, ls[lvl].Wo, ls[lvl].Hm, ls[lvl].Wm,
                                    desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, ls[lvl].Hin, ls[lvl].Win,
-                                   scratch, scratch_bytes, stream));
+                                   scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST));
     }
     swf_head_params hp{arena + L->h_c1w, arena + L->h_c1b, arena + L->h_g, arena + L->h_b, arena + L->h_m, arena + L->h_v,
                        arena + L->h_c2w, arena + L->h_c2b};
