@@ -13,12 +13,18 @@ struct GemmProb {
     const float* res;   // [M][N] row stride ldo, added to the result, or nullptr
     float* out;         // [M][N] row stride ldo
 };
-struct GemmBatch { GemmProb p[kMaxProb]; };
+struct GemmBatch {
+    GemmProb p[kMaxProb];
+    float* scratch = nullptr;        // optional: room for split-K partials (fast tier); nullptr disables split-K
+    int64_t scratch_floats = 0;
+};
 
 // out = act(A . W^T + bias) (+ res); act: 0 none, 1 ELU(alpha=1).  Exact fp32 (f32-input MFMA).
 int launch_gemm_f32(const GemmBatch& batch, int nprob, int M, int N, int K, int lda, int ldo, int act,
                     hipStream_t stream);
 
+// K slices the fast-tier GEMM uses for a given K (scratch need = slices * nprob * M * N floats)
+int gemm_splitk_for(int K);
 // Same contract in fast-tier arithmetic: split-bf16 (bf16x3) operands on the bf16 MFMA, fp32 accumulate.
 int launch_gemm_bf16x3(const GemmBatch& batch, int nprob, int M, int N, int K, int lda, int ldo, int act,
                        hipStream_t stream);

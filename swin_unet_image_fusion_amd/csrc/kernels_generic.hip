@@ -135,9 +135,14 @@ __device__ __forceinline__ void split4(const float4 v, bf16x4_t& hi, bf16x4_t& l
     }
 }
 
+// split-K: blockIdx.z = problem * splitk + slice; a slice covers kchunk (multiple of 32) of K and, when
+// splitk > 1, writes its raw partial tile to batch.scratch[(z)][M][N]; gemm_splitk_reduce_kernel sums the
+// slices in fixed order (bitwise reproducible, no atomics) and applies bias / activation / residual.
 __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmBatch batch, int M, int N, int K, int lda, int ldo,
-                                                           int act, int vecA, int vecW) {
-    const GemmProb pr = batch.p[blockIdx.z];
+                                                           int act, int vecA, int vecW, int splitk, int kchunk) {
+    const int prob = blockIdx.z / splitk, slice = blockIdx.z % splitk;
+    const GemmProb pr = batch.p[prob];
+    const int kbeg = slice * kchunk, kend = min(K, kbeg + kchunk);
     __shared__ __attribute__((aligned(16))) bf16_t As_hi[GBM * XLD], As_lo[GBM * XLD], Ws_hi[GBN * XLD], Ws_lo[GBN * XLD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wr = wave >> 1, wc = wave & 1;
@@ -159,13 +164,13 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmBatch batch, int M
         v0 = make_float4(0.f, 0.f, 0.f, 0.f);
         v1 = v0;
         if (!in_range) return;
-        if (vec && gk + 8 <= K) {
+        if (vec && gk + 8 <= kend) {
             v0 = *reinterpret_cast<const float4*>(base + row_off + gk);
             v1 = *reinterpret_cast<const float4*>(base + row_off + gk + 4);
         } else {
             float t[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) t[i] = (gk + i < K) ? base[row_off + gk + i] : 0.f;
+            for (int i = 0; i < 8; ++i) t[i] = (gk + i < kend) ? base[row_off + gk + i] : 0.f;
             v0 = make_float4(t[0], t[1], t[2], t[3]);
             v1 = make_float4(t[4], t[5], t[6], t[7]);
         }
@@ -182,14 +187,14 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmBatch batch, int M
     };
 
     float4 a0, a1, w0, w1;
-    load8(pr.A, arow, a_in, vecA, lk, a0, a1);
-    load8(pr.W, wrow, w_in, vecW, lk, w0, w1);
-    for (int k0 = 0; k0 < K; k0 += XBK) {
+    load8(pr.A, arow, a_in, vecA, kbeg + lk, a0, a1);
+    load8(pr.W, wrow, w_in, vecW, kbeg + lk, w0, w1);
+    for (int k0 = kbeg; k0 < kend; k0 += XBK) {
         __syncthreads();   // the previous k-step's fragment reads are done
         stash(As_hi, As_lo, a0, a1);
         stash(Ws_hi, Ws_lo, w0, w1);
         __syncthreads();
-        if (k0 + XBK < K) {   // issue the next tile's loads; they land while the MFMAs run
+        if (k0 + XBK < kend) {   // issue the next tile's loads; they land while the MFMAs run
             load8(pr.A, arow, a_in, vecA, k0 + XBK + lk, a0, a1);
             load8(pr.W, wrow, w_in, vecW, k0 + XBK + lk, w0, w1);
         }
@@ -213,17 +218,22 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmBatch batch, int M
                 acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ah[m], bh[n], acc[m][n], 0, 0, 0);
             }
     }
+    float* part = splitk > 1 ? batch.scratch + (int64_t)blockIdx.z * M * N : nullptr;
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
         for (int n = 0; n < 2; ++n) {
             const int col = bcol + wc * 32 + n * 16 + fr;
             if (col >= N) continue;
-            const float bv = pr.bias ? pr.bias[col] : 0.f;
+            const float bv = (pr.bias && !part) ? pr.bias[col] : 0.f;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int row = brow + wr * 32 + m * 16 + fq * 4 + j;
                 if (row >= M) continue;
+                if (part) {
+                    part[(int64_t)row * N + col] = acc[m][n][j];
+                    continue;
+                }
                 float v = acc[m][n][j] + bv;
                 if (act == 1) v = elu1(v);
                 const int64_t o = (int64_t)row * ldo + col;
@@ -233,6 +243,29 @@ __global__ __launch_bounds__(256) void gemm_bf16x3_kernel(GemmBatch batch, int M
         }
 }
 
+__global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmBatch batch, int M, int N, int ldo, int act, int splitk) {
+    const int prob = blockIdx.y;
+    const GemmProb pr = batch.p[prob];
+    const int64_t total = (int64_t)M * N;
+    const float* part = batch.scratch + (int64_t)prob * splitk * total;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int col = (int)(e % N);
+        const int64_t row = e / N;
+        float v = 0.f;
+        for (int s = 0; s < splitk; ++s) v += part[s * total + e];   // fixed order
+        if (pr.bias) v += pr.bias[col];
+        if (act == 1) v = elu1(v);
+        const int64_t o = row * ldo + col;
+        if (pr.res) v = pr.res[o] + v;
+        pr.out[o] = v;
+    }
+}
+
+// K slices as a function of K ALONE: the summation order of an output element must not depend on how many
+// tokens (images) share the launch, or batch shards would stop being bit-identical to the unsharded run
+// (the multi-GPU contract).  Long-K GEMMs are exactly the small-M, weight-streaming ones of the deep levels.
+int gemm_splitk_for(int K) { return K >= 1024 ? 4 : (K >= 384 ? 2 : 1); }
+
 int launch_gemm_bf16x3(const GemmBatch& batch, int nprob, int M, int N, int K, int lda, int ldo, int act,
                        hipStream_t stream) {
     if (M <= 0 || N <= 0 || K <= 0) return fail(SWF_ERR_BAD_SHAPE, "gemm: empty problem %dx%dx%d", M, N, K);
@@ -241,9 +274,19 @@ int launch_gemm_bf16x3(const GemmBatch& batch, int nprob, int M, int N, int K, i
         if (reinterpret_cast<uintptr_t>(batch.p[i].A) % 16) vecA = 0;
         if (reinterpret_cast<uintptr_t>(batch.p[i].W) % 16) vecW = 0;
     }
-    dim3 grid(cdiv(M, GBM), cdiv(N, GBN), nprob);
-    hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, stream, batch, M, N, K, lda, ldo, act, vecA, vecW);
-    return check_launch("gemm_bf16x3");
+    int splitk = gemm_splitk_for(K);
+    if (splitk > 1 && (!batch.scratch || (int64_t)splitk * nprob * M * N > batch.scratch_floats))
+        return fail(SWF_ERR_WORKSPACE, "gemm: split-K scratch too small (%d slices of %d x %d x %d)", splitk, nprob, M, N);
+    const int kchunk = cdiv(cdiv(K, splitk), XBK) * XBK;
+    dim3 grid(cdiv(M, GBM), cdiv(N, GBN), nprob * splitk);
+    hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, stream, batch, M, N, K, lda, ldo, act, vecA, vecW, splitk, kchunk);
+    SWF_TRY(check_launch("gemm_bf16x3"));
+    if (splitk > 1) {
+        dim3 rgrid((unsigned)std::min<int64_t>(cdiv64((int64_t)M * N, 256), 2048), nprob);
+        hipLaunchKernelGGL(gemm_splitk_reduce_kernel, rgrid, dim3(256), 0, stream, batch, M, N, ldo, act, splitk);
+        return check_launch("gemm_splitk_reduce");
+    }
+    return SWF_OK;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -33,6 +33,12 @@ static int check_attn_desc(const swf_attn_desc* d, int B, int H, int W) {
     return SWF_OK;
 }
 
+// room for the split-K partials of the largest fast-tier GEMM of a unit
+static int64_t splitk_need(int K, int64_t nprob_m_n) {
+    const int sk = gemm_splitk_for(K);
+    return sk > 1 ? sk * nprob_m_n : 0;
+}
+
 // ---- generic composition -----------------------------------------------------------------
 // Q/K/V projections (three GEMM problems per stream in one launch), attention core, output
 // projection (+ residual).  qsrc/ksrc/vsrc are [N][C] token-major inputs per stream.
@@ -48,8 +54,11 @@ static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn
         for (int i = 0; i < 3; ++i) qkv[s][i] = ws.floats(N * HD);
         o[s] = ws.floats(N * HD);
     }
+    const int64_t sk_floats = fast ? std::max(splitk_need(C, 3 * nstream * N * HD), splitk_need(HD, nstream * N * C)) : 0;
+    float* sk = fast ? ws.floats(sk_floats) : nullptr;
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "attention workspace too small (need %zu B)", ws.used);
     GemmBatch gb{};
+    gb.scratch = sk; gb.scratch_floats = sk_floats;
     for (int s = 0; s < nstream; ++s) {
         const swf_linear* lin[3] = {&prm[s]->q, &prm[s]->k, &prm[s]->v};
         const float* src[3] = {qsrc[s], ksrc[s], vsrc[s]};
@@ -68,6 +77,7 @@ static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn
         SWF_TRY(launch_attn_core(ab, nstream, HD, HD, HD, HD, B, H, W, d.win_h, d.win_w, d.heads, d.head_dim, d.shift, stream));
     }
     GemmBatch pb{};
+    pb.scratch = sk; pb.scratch_floats = sk_floats;
     for (int s = 0; s < nstream; ++s)
         pb.p[s] = GemmProb{o[s], prm[s]->proj.weight, prm[s]->proj.bias, residual ? residual[s] : nullptr, out[s]};
     SWF_TRY(launch_gemm(fast, pb, nstream, (int)N, C, HD, HD, C, 0, stream));
@@ -78,7 +88,7 @@ static size_t attention_generic_ws(const swf_attn_desc& d, int nstream, int B, i
     const int64_t N = (int64_t)B * H * W, HD = (int64_t)d.heads * d.head_dim;
     size_t total = 0;
     for (int s = 0; s < nstream; ++s) total += carve_bytes({N * HD, N * HD, N * HD, N * HD});
-    return total;
+    return total + carve_bytes({std::max(splitk_need(d.channels, 3 * nstream * N * HD), splitk_need((int)HD, nstream * N * d.channels))});
 }
 
 static int check_stream_params(const swf_block_stream_params* p, const char* which, bool need_attn, bool need_mlp) {
@@ -120,12 +130,16 @@ static int mlp_halfblock_generic(const swf_block_desc* desc, const swf_block_str
     const int C = desc->attn.channels, hid = desc->hidden;
     float* xn[2] = {ws.floats(N * C), nstream == 2 ? ws.floats(N * C) : nullptr};
     float* hb[2] = {ws.floats(N * hid), nstream == 2 ? ws.floats(N * hid) : nullptr};
+    const int fast = desc->precision == SWF_PREC_FAST;
+    const int64_t sk_floats = fast ? std::max(splitk_need(C, nstream * N * hid), splitk_need(hid, nstream * N * C)) : 0;
+    float* sk = fast ? ws.floats(sk_floats) : nullptr;
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "MLP half-block workspace too small");
     LnBatch lb{};
     lb.p[0] = LnProb{x_in, xn[0], px->ln2.gamma, px->ln2.beta};
     if (nstream == 2) lb.p[1] = LnProb{y_in, xn[1], py->ln2.gamma, py->ln2.beta};
     SWF_TRY(launch_layernorm(lb, nstream, N, C, 0, stream));
     GemmBatch g1{}, g2{};
+    g1.scratch = g2.scratch = sk; g1.scratch_floats = g2.scratch_floats = sk_floats;
     const swf_block_stream_params* pp[2] = {px, py};
     const float* res[2] = {x_in, y_in};
     float* out[2] = {x_out, y_out};
@@ -133,7 +147,6 @@ static int mlp_halfblock_generic(const swf_block_desc* desc, const swf_block_str
         g1.p[s] = GemmProb{xn[s], pp[s]->fc1.weight, pp[s]->fc1.bias, nullptr, hb[s]};
         g2.p[s] = GemmProb{hb[s], pp[s]->fc2.weight, pp[s]->fc2.bias, res[s], out[s]};
     }
-    const int fast = desc->precision == SWF_PREC_FAST;
     SWF_TRY(launch_gemm(fast, g1, nstream, (int)N, hid, C, C, hid, 1, stream));
     SWF_TRY(launch_gemm(fast, g2, nstream, (int)N, C, hid, hid, C, 0, stream));
     return SWF_OK;
@@ -145,6 +158,7 @@ static size_t block_generic_ws(const swf_block_desc* d, int nstream, int B, int 
     for (int s = 0; s < nstream; ++s) a += carve_bytes({N * d->attn.channels});
     a += attention_generic_ws(d->attn, nstream, B, H, W);
     for (int s = 0; s < nstream; ++s) m += carve_bytes({N * d->attn.channels}) + carve_bytes({N * d->hidden});
+    m += carve_bytes({std::max(splitk_need(d->attn.channels, nstream * N * d->hidden), splitk_need(d->hidden, nstream * N * d->attn.channels))});
     return std::max(a, m);
 }
 
@@ -213,9 +227,12 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
     float* a[2];
     float* z[2];
     for (int s = 0; s < nstream; ++s) { a[s] = ws.floats(N * K); z[s] = ws.floats(N * Cout); }
+    const int64_t sk_floats = fast ? splitk_need(K, nstream * N * Cout) : 0;
+    float* sk = fast ? ws.floats(sk_floats) : nullptr;
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "patch-merge workspace too small (need %zu B)", ws.used);
     PtrPair pp{};
     GemmBatch gb{};
+    gb.scratch = sk; gb.scratch_floats = sk_floats;
     LnBatch lb{};
     for (int s = 0; s < nstream; ++s) {
         pp.in[s] = in[s]; pp.out[s] = a[s];
@@ -246,9 +263,12 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
         z[s] = ws.floats(N * Kz);
         zn[s] = ws.floats(N * Kz);
     }
+    const int64_t sk_floats = fast ? splitk_need(Cin, nstream * N * Kz) : 0;
+    float* sk = fast ? ws.floats(sk_floats) : nullptr;
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "patch-unmerge workspace too small (need %zu B)", ws.used);
     PtrPair cp{}, sp{};
     GemmBatch gb{};
+    gb.scratch = sk; gb.scratch_floats = sk_floats;
     LnBatch lb{};
     for (int s = 0; s < nstream; ++s) {
         cp.in[s] = in[s]; cp.out[s] = cr[s];
@@ -269,9 +289,11 @@ static size_t patch_ws(int nstream, int B, int H, int W, int Cin, int Cout, int 
         if (merge_shapes(H, W, mh, mw, wh, ww, &Hm, &Wm, &Ho, &Wo) != SWF_OK) return 0;
         const int64_t N = (int64_t)B * Ho * Wo;
         for (int s = 0; s < nstream; ++s) total += carve_bytes({N * mh * mw * Cin, N * Cout});
+        total += carve_bytes({splitk_need(mh * mw * Cin, nstream * N * Cout)});
     } else {
         const int64_t N = (int64_t)B * H * W;   // upper bound: uncropped map
         for (int s = 0; s < nstream; ++s) total += carve_bytes({N * Cin, N * mh * mw * Cout, N * mh * mw * Cout});
+        total += carve_bytes({splitk_need(Cin, (int64_t)nstream * N * mh * mw * Cout)});
     }
     return total;
 }
