@@ -89,8 +89,15 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     weight_bytes = 2 * (4 * c * hd + 3 * hd + c + tbl + 2 * c) * 4
     alg_bytes = 4 * n_tok * c * BYTES_PER_ELEM + weight_bytes
     achieved = alg_bytes / (ms * 1e-3) / 1e9
+    # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE / WRITE_SIZE collected in
+    # separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes); only valid for the default workload
+    traffic = None
+    tj = os.path.join(REPO, "profiles", "r01d_traffic.json")
+    if os.path.exists(tj) and batch == 16 and size == 256 and c == 24 and precision == "fast":
+        with open(tj) as f:
+            traffic = json.load(f).get("hbm_bytes_per_launch")
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": None,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
             "kernel": "level-0 shifted-window BasicBlock launch (swf_basic_block_fwd)",
             "ms_per_launch": round(ms, 4), "algorithmic_bytes": alg_bytes, "bytes_per_elem": BYTES_PER_ELEM}
 

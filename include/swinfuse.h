@@ -212,6 +212,16 @@ int swf_model_forward(const swf_model_desc* desc, const float* arena, const floa
                       float* out, int32_t B, int32_t H, int32_t W,
                       void* workspace, size_t workspace_bytes, swf_stream_t stream);
 
+/* Optional: derive the fused kernels' weight images (split-bf16, pre-scaled Wq, masked bias matrices) ONCE
+ * instead of per call.  `packed` is a caller-owned device buffer of swf_model_packed_bytes(desc) bytes
+ * (0 when no level of this model uses a fused kernel); repack after the arena changes. */
+size_t swf_model_packed_bytes(const swf_model_desc* desc);
+int swf_model_pack_weights(const swf_model_desc* desc, const float* arena, void* packed, size_t packed_bytes,
+                           swf_stream_t stream);
+int swf_model_forward_packed(const swf_model_desc* desc, const float* arena, const void* packed,
+                             const float* ir, const float* vis, float* out, int32_t B, int32_t H, int32_t W,
+                             void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 int swf_version(void);                     /* major*1000 + minor */
 const char* swf_last_error_string(void);   /* thread-local, never NULL */

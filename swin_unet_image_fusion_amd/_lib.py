@@ -95,6 +95,9 @@ SIGNATURES = {
     "swf_model_arena_elems": (_i64, [P(ModelDesc)]),
     "swf_model_workspace_bytes": (_sz, [P(ModelDesc), _i32, _i32, _i32]),
     "swf_model_forward": (C.c_int, [P(ModelDesc), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_model_packed_bytes": (_sz, [P(ModelDesc)]),
+    "swf_model_pack_weights": (C.c_int, [P(ModelDesc), _vp, _vp, _sz, _vp]),
+    "swf_model_forward_packed": (C.c_int, [P(ModelDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

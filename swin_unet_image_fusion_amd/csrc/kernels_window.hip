@@ -17,7 +17,6 @@
 #include "kernels_window.h"
 
 #include <algorithm>
-#include <cstdlib>
 #include <mutex>
 
 namespace swf {
@@ -80,7 +79,6 @@ struct WinArgs {
     float* out[2];
     const char* packed[2];
     int B, H, W, shift, cross;
-    int dbg_skip;   // TEMP ablation mask
 };
 
 // ------------------------------------------------------------------------------------------
@@ -289,11 +287,11 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         if (win + (int)gridDim.x < nwin) SWF_PREFETCH(win + gridDim.x);
 
         // ---- LN1 -> A image (own rows) ----
-        if (!(args.dbg_skip & 1)) layernorm_rows<G>(my_resid, my_ahi, my_alo, wvec(ws), G::v_ln1g, G::v_ln1b, lane);
+        layernorm_rows<G>(my_resid, my_ahi, my_alo, wvec(ws), G::v_ln1g, G::v_ln1b, lane);
 
         // ---- Q, K, V projections of the own rows.  Q for the own stream; K and V for the stream whose attention
         //      reads these tokens as keys: itself, or the other one in a cross block (a002:67-82) ----
-        if (!(args.dbg_skip & 2)) {
+        {
             Frag<KS> x;
             load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
             const int kvs = args.cross ? 1 - ws : ws;
@@ -331,7 +329,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         __syncthreads();   // all Q / K / V^T rows of the window are in place
 
         // ---- attention.  wave -> (stream, 32-query block, 4 heads) ----
-        if (!(args.dbg_skip & 4)) {
+        {
             const int s = wave >> 2, qb = (wave >> 1) & 1, h0 = (wave & 1) * 4;
             const int r = lane & 31, hf = lane >> 5;
             const int variant = args.shift ? ((wy == nwy - 1) * 2 + (wx == nwx - 1)) : 0;
@@ -436,7 +434,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         __syncthreads();   // O rows complete
 
         // ---- output projection + residual (own rows; transposed tiles: a lane holds 4 channels of one token) ----
-        if (!(args.dbg_skip & 8)) {
+        {
             Frag<KS> x;
             load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
 #pragma unroll
@@ -457,12 +455,12 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         }
 
         // ---- LN2 -> A image (own rows) ----
-        if (!(args.dbg_skip & 16)) layernorm_rows<G>(my_resid, my_ahi, my_alo, wvec(ws), G::v_ln2g, G::v_ln2b, lane);
+        layernorm_rows<G>(my_resid, my_ahi, my_alo, wvec(ws), G::v_ln2g, G::v_ln2b, lane);
 
         // ---- MLP, own rows, walking the hidden dimension in chunks of 32: fc1 + ELU for the chunk -> split-bf16
         //      image over the wave's own A rows (xn2 already sits in registers) -> one k-step of fc2.  The hidden
         //      activations never exist as a whole. ----
-        if (!(args.dbg_skip & 32)) {
+        {
             Frag<KS> x;
             load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
             f32x4 out[G::NTC];
@@ -845,7 +843,6 @@ int launch_window_block(const swf_block_desc& d, const void* packed_x, const voi
     a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
     a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
-    a.dbg_skip = getenv("SWF_DEBUG_SKIP") ? atoi(getenv("SWF_DEBUG_SKIP")) : 0;
     const int nwin = B * (H / 8) * (W / 8);
 #define X(C, HID) if (dims_match(d, C, HID)) return launch_t<C, HID>(a, nwin, stream);
     SWF_WINDOW_SHAPES(X)

@@ -180,8 +180,10 @@ static int check_block(const swf_block_desc* desc, const swf_block_stream_params
 static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_params* px,
                             const swf_block_stream_params* py, const float* x_in, const float* y_in, float* x_out,
                             float* y_out, int B, int H, int W, void* workspace, size_t workspace_bytes,
-                            hipStream_t stream) {
+                            hipStream_t stream, const void* prepacked_x = nullptr, const void* prepacked_y = nullptr) {
     if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W)) {
+        if (prepacked_x && prepacked_y)   // model path: weights were packed once (swf_model_pack_weights)
+            return launch_window_block(*desc, prepacked_x, prepacked_y, x_in, y_in, x_out, y_out, B, H, W, stream);
         // block-level entry: pack this block's weights into the workspace, then one fused launch
         const size_t pb = window_block_packed_bytes(*desc);
         if (!workspace || workspace_bytes < 2 * pb) return fail(SWF_ERR_WORKSPACE, "fused block workspace too small (need %zu B)", 2 * pb);
@@ -452,19 +454,48 @@ static swf_block_desc level_block_desc(const swf_model_desc* d, int lvl, bool en
     return b;
 }
 
+// `packed`: nullptr, or the 8 packed weight images of the stage laid out [block 0..3][stream x,y] at a
+// stride of window_block_packed_bytes(desc)
 static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                             const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
-                            void* workspace, size_t workspace_bytes, hipStream_t stream) {
+                            void* workspace, size_t workspace_bytes, hipStream_t stream, const char* packed = nullptr) {
     const float* xi = x_in;
     const float* yi = y_in;
+    const size_t pb = packed ? window_block_packed_bytes(*desc) : 0;
     for (int i = 0; i < 4; ++i) {
         swf_block_desc d = *desc;
         d.cross = i >= 2;          // self pair first, then cross pair (a012:72-73)
         d.attn.shift = i & 1;      // normal window, then shifted window (a009:102-105)
-        SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream));
+        const void* pkx = (packed && pb) ? packed + (size_t)(2 * i) * pb : nullptr;
+        const void* pky = (packed && pb) ? packed + (size_t)(2 * i + 1) * pb : nullptr;
+        SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream, pkx, pky));
         xi = x_out; yi = y_out;
     }
     return SWF_OK;
+}
+
+// byte offset of each stage's packed images inside the model-level packed buffer (encoder stages first)
+struct PackedPlan {
+    size_t enc[SWF_MAX_LEVELS], dec[SWF_MAX_LEVELS], total;
+    bool enc_on[SWF_MAX_LEVELS], dec_on[SWF_MAX_LEVELS];
+};
+static PackedPlan packed_plan(const swf_model_desc* d) {
+    PackedPlan p{};
+    size_t off = 0;
+    for (int s = 0; s < d->levels; ++s) {
+        swf_block_desc be = level_block_desc(d, s, true);
+        be.precision = SWF_PREC_FAST;
+        const size_t pb = window_block_packed_bytes(be);
+        p.enc_on[s] = pb > 0; p.enc[s] = off; off += 8 * pb;
+    }
+    for (int j = 0; j < d->levels; ++j) {
+        swf_block_desc bd = level_block_desc(d, d->levels - 1 - j, false);
+        bd.precision = SWF_PREC_FAST;
+        const size_t pb = window_block_packed_bytes(bd);
+        p.dec_on[j] = pb > 0; p.dec[j] = off; off += 8 * pb;
+    }
+    p.total = off;
+    return p;
 }
 
 }  // namespace swf
@@ -690,9 +721,41 @@ size_t swf_model_workspace_bytes(const swf_model_desc* desc, int32_t B, int32_t 
     return total + model_scratch_bytes(desc, B, ls) + 256;
 }
 
-int swf_model_forward(const swf_model_desc* desc, const float* arena, const float* ir, const float* vis, float* out,
-                      int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream_) {
+size_t swf_model_packed_bytes(const swf_model_desc* desc) {
+    if (check_model_desc(desc) != SWF_OK) return 0;
+    return packed_plan(desc).total;
+}
+
+int swf_model_pack_weights(const swf_model_desc* desc, const float* arena, void* packed, size_t packed_bytes, swf_stream_t stream_) {
     SWF_TRY(check_model_desc(desc));
+    if (!arena) return fail(SWF_ERR_NULL, "model_pack_weights: NULL arena");
+    const PackedPlan plan = packed_plan(desc);
+    if (plan.total == 0) return SWF_OK;
+    if (!packed || packed_bytes < plan.total) return fail(SWF_ERR_WORKSPACE, "packed buffer too small (need %zu B)", plan.total);
+    const ModelLayout* L = get_layout(desc);
+    hipStream_t stream = as_stream(stream_);
+    char* base = static_cast<char*>(packed);
+    for (int pass = 0; pass < 2; ++pass)
+        for (int k = 0; k < desc->levels; ++k) {
+            const bool enc = pass == 0;
+            if (!(enc ? plan.enc_on[k] : plan.dec_on[k])) continue;
+            swf_block_desc bd = level_block_desc(desc, enc ? k : desc->levels - 1 - k, enc);
+            bd.precision = SWF_PREC_FAST;
+            const size_t pb = window_block_packed_bytes(bd);
+            char* dst = base + (enc ? plan.enc[k] : plan.dec[k]);
+            for (int i = 0; i < 4; ++i) {
+                const swf_block_stream_params px = make_stream_params(arena, enc ? L->enc_blk[k][i][0] : L->dec_blk[k][i][0]);
+                const swf_block_stream_params py = make_stream_params(arena, enc ? L->enc_blk[k][i][1] : L->dec_blk[k][i][1]);
+                SWF_TRY(pack_window_block(bd, px, py, dst + (size_t)(2 * i) * pb, dst + (size_t)(2 * i + 1) * pb, stream));
+            }
+        }
+    return SWF_OK;
+}
+
+static int model_forward_impl(const swf_model_desc* desc, const float* arena, const char* packed, const float* ir, const float* vis, float* out,
+                              int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream_) {
+    SWF_TRY(check_model_desc(desc));
+    const PackedPlan plan = packed_plan(desc);
     if (!arena || !ir || !vis || !out) return fail(SWF_ERR_NULL, "model_forward: NULL tensor");
     if (B <= 0) return fail(SWF_ERR_BAD_SHAPE, "model_forward: empty batch");
     LevelShape ls[SWF_MAX_LEVELS];
@@ -723,7 +786,8 @@ int swf_model_forward(const swf_model_desc* desc, const float* arena, const floa
         swf_block_stream_params px[4], py[4];
         for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->enc_blk[s][i][0]); py[i] = make_stream_params(arena, L->enc_blk[s][i][1]); }
         swf_block_desc bd = level_block_desc(desc, s, true);
-        SWF_TRY(block_pair4_impl(&bd, px, py, act[s][0], act[s][1], act[s][0], act[s][1], B, ls[s].Ho, ls[s].Wo, scratch, scratch_bytes, stream));
+        SWF_TRY(block_pair4_impl(&bd, px, py, act[s][0], act[s][1], act[s][0], act[s][1], B, ls[s].Ho, ls[s].Wo, scratch, scratch_bytes, stream,
+                                 (packed && plan.enc_on[s]) ? packed + plan.enc[s] : nullptr));
         cur[0] = act[s][0]; cur[1] = act[s][1];
     }
     // decoder (a013:221-227): the skip add of stage j+1 is folded into stage j's unmerge epilogue,
@@ -733,7 +797,8 @@ int swf_model_forward(const swf_model_desc* desc, const float* arena, const floa
         swf_block_stream_params px[4], py[4];
         for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->dec_blk[j][i][0]); py[i] = make_stream_params(arena, L->dec_blk[j][i][1]); }
         swf_block_desc bd = level_block_desc(desc, lvl, false);
-        SWF_TRY(block_pair4_impl(&bd, px, py, act[lvl][0], act[lvl][1], act[lvl][0], act[lvl][1], B, ls[lvl].Ho, ls[lvl].Wo, scratch, scratch_bytes, stream));
+        SWF_TRY(block_pair4_impl(&bd, px, py, act[lvl][0], act[lvl][1], act[lvl][0], act[lvl][1], B, ls[lvl].Ho, ls[lvl].Wo, scratch, scratch_bytes, stream,
+                                 (packed && plan.dec_on[j]) ? packed + plan.dec[j] : nullptr));
         swf_patch_params pm[2] = {patch_params(L->dec_patch[j][0]), patch_params(L->dec_patch[j][1])};
         const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
         const float* ins[2] = {act[lvl][0], act[lvl][1]};
@@ -748,6 +813,16 @@ int swf_model_forward(const swf_model_desc* desc, const float* arena, const floa
     float* tmp = static_cast<float*>(scratch);
     SWF_TRY(launch_head_conv1(full[0], full[1], tmp, hp, B, H, W, desc->head_ksize, stream));
     return launch_head_conv2(tmp, out, hp, B, H, W, desc->head_ksize, stream);
+}
+
+int swf_model_forward(const swf_model_desc* desc, const float* arena, const float* ir, const float* vis, float* out,
+                      int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    return model_forward_impl(desc, arena, nullptr, ir, vis, out, B, H, W, workspace, workspace_bytes, stream);
+}
+
+int swf_model_forward_packed(const swf_model_desc* desc, const float* arena, const void* packed, const float* ir, const float* vis,
+                             float* out, int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    return model_forward_impl(desc, arena, static_cast<const char*>(packed), ir, vis, out, B, H, W, workspace, workspace_bytes, stream);
 }
 
 }  // extern "C"

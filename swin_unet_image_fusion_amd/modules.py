@@ -628,6 +628,7 @@ class MyModel(_FwdAlias, nn.Module):
         self.precision = "fast"
         self._arena: Optional[Tensor] = None
         self._arena_key = None
+        self._packed: Optional[Tensor] = None
 
         enc, dec = deque(), deque()
         for j in range(len(self.in_dims_list) - 1, -1, -1):   # a013:154-207
@@ -674,10 +675,10 @@ class MyModel(_FwdAlias, nn.Module):
         """Drop the packed arena; it is rebuilt from the current parameters at the next forward.
         Called automatically after load_state_dict() and .to(); call it by hand after editing
         parameters in place."""
-        self._arena, self._arena_key = None, None
+        self._arena, self._arena_key, self._packed = None, None, None
 
     def _apply(self, fn, *a, **kw):
-        self._arena, self._arena_key = None, None
+        self._arena, self._arena_key, self._packed = None, None, None
         return super()._apply(fn, *a, **kw)
 
     def param_layout(self):
@@ -710,7 +711,19 @@ class MyModel(_FwdAlias, nn.Module):
                 host[off:off + num] = t.detach().reshape(-1).to("cpu", torch.float32)
             self._arena = host.to(device)
             self._arena_key = key
+            self._packed = None
         return self._arena
+
+    def _get_packed(self, arena: Tensor) -> Optional[Tensor]:
+        """Kernel-layout weight images of the fused levels, derived once per arena (swf_model_pack_weights)."""
+        if self._packed is None:
+            lib, desc = L.lib(), self._model_desc()
+            n = lib.swf_model_packed_bytes(C.byref(desc))
+            buf = torch.empty(max(n, 16), dtype=torch.uint8, device=arena.device)
+            if n:
+                L.check(lib.swf_model_pack_weights(C.byref(desc), _ptr(arena), buf.data_ptr(), n, _stream(arena.device)))
+            self._packed = buf
+        return self._packed
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, in_x: Tensor, in_y: Tensor) -> Tensor:
@@ -728,6 +741,11 @@ class MyModel(_FwdAlias, nn.Module):
         lib, desc = L.lib(), self._model_desc()
         need = lib.swf_model_workspace_bytes(C.byref(desc), b, h, w)
         ws, wsn = _workspace(need, x.device)
-        L.check(lib.swf_model_forward(C.byref(desc), _ptr(arena), _ptr(x), _ptr(y), _ptr(out), b, h, w, ws, wsn,
-                                      _stream(x.device)))
+        if desc.precision == L.PREC_FAST:
+            packed = self._get_packed(arena)
+            L.check(lib.swf_model_forward_packed(C.byref(desc), _ptr(arena), packed.data_ptr(), _ptr(x), _ptr(y), _ptr(out),
+                                                 b, h, w, ws, wsn, _stream(x.device)))
+        else:
+            L.check(lib.swf_model_forward(C.byref(desc), _ptr(arena), _ptr(x), _ptr(y), _ptr(out), b, h, w, ws, wsn,
+                                          _stream(x.device)))
         return out
