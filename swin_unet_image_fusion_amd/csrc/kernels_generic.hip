@@ -248,6 +248,28 @@ __global__ __launch_bounds__(256) void gemm_splitk_reduce_kernel(GemmBatch batch
     const GemmProb pr = batch.p[prob];
     const int64_t total = (int64_t)M * N;
     const float* part = batch.scratch + (int64_t)prob * splitk * total;
+    if ((N & 3) == 0 && (ldo & 3) == 0) {   // four consecutive columns per thread (scratch and outputs are 16-B aligned)
+        const int64_t total4 = total >> 2;
+        for (int64_t e4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (int64_t)gridDim.x * blockDim.x) {
+            const int64_t e = e4 << 2;
+            const int col = (int)(e % N);
+            const int64_t row = e / N;
+            float4 v = *reinterpret_cast<const float4*>(part + e);
+            for (int s = 1; s < splitk; ++s) {   // fixed order
+                const float4 t = *reinterpret_cast<const float4*>(part + s * total + e);
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+            if (pr.bias) { v.x += pr.bias[col]; v.y += pr.bias[col + 1]; v.z += pr.bias[col + 2]; v.w += pr.bias[col + 3]; }
+            if (act == 1) { v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w); }
+            const int64_t o = row * ldo + col;
+            if (pr.res) {
+                const float4 r = *reinterpret_cast<const float4*>(pr.res + o);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            *reinterpret_cast<float4*>(pr.out + o) = v;
+        }
+        return;
+    }
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
         const int col = (int)(e % N);
         const int64_t row = e / N;
@@ -282,7 +304,7 @@ int launch_gemm_bf16x3(const GemmBatch& batch, int nprob, int M, int N, int K, i
     hipLaunchKernelGGL(gemm_bf16x3_kernel, grid, dim3(256), 0, stream, batch, M, N, K, lda, ldo, act, vecA, vecW, splitk, kchunk);
     SWF_TRY(check_launch("gemm_bf16x3"));
     if (splitk > 1) {
-        dim3 rgrid((unsigned)std::min<int64_t>(cdiv64((int64_t)M * N, 256), 2048), nprob);
+        dim3 rgrid((unsigned)std::min<int64_t>(cdiv64((int64_t)M * N, 1024), 2048), nprob);
         hipLaunchKernelGGL(gemm_splitk_reduce_kernel, rgrid, dim3(256), 0, stream, batch, M, N, ldo, act, splitk);
         return check_launch("gemm_splitk_reduce");
     }
@@ -316,7 +338,76 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnBatch batch, int64_t t
     }
 }
 
+// Single-pass variant for C % 4 == 0: the token row lives in registers (L lanes per token, each lane
+// NCH float4 chunks at stride L), one read and one write of the tensor.
+template <int NCH>
+__global__ __launch_bounds__(256) void layernorm_vec_kernel(LnBatch batch, int64_t tokens, int C, int L, int elu) {
+    const LnProb pr = batch.p[blockIdx.y];
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tok = gt / L;
+    const int sub = (int)(gt % L);
+    const bool live = tok < tokens;
+    const int chunks = C >> 2;
+    const float4* x = reinterpret_cast<const float4*>(pr.in + (live ? tok : 0) * C);
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = sub + i * L;
+        v[i] = (live && ch < chunks) ? x[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (sub + i * L < chunks) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+    if (!live) return;
+    float4* y = reinterpret_cast<float4*>(pr.out + tok * C);
+    const float4* g4 = reinterpret_cast<const float4*>(pr.gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(pr.beta);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = sub + i * L;
+        if (ch < chunks) {
+            const float4 g = g4[ch], b = b4[ch];
+            float4 r;
+            r.x = (v[i].x - mean) * rstd * g.x + b.x;
+            r.y = (v[i].y - mean) * rstd * g.y + b.y;
+            r.z = (v[i].z - mean) * rstd * g.z + b.z;
+            r.w = (v[i].w - mean) * rstd * g.w + b.w;
+            if (elu) { r.x = elu1(r.x); r.y = elu1(r.y); r.z = elu1(r.z); r.w = elu1(r.w); }
+            y[ch] = r;
+        }
+    }
+}
+
 int launch_layernorm(const LnBatch& batch, int nprob, int64_t tokens, int C, int elu, hipStream_t stream) {
+    bool vec = (C % 4 == 0) && C <= 1024;
+    for (int i = 0; i < nprob; ++i) {
+        const uintptr_t bits = reinterpret_cast<uintptr_t>(batch.p[i].in) | reinterpret_cast<uintptr_t>(batch.p[i].out) |
+                               reinterpret_cast<uintptr_t>(batch.p[i].gamma) | reinterpret_cast<uintptr_t>(batch.p[i].beta);
+        if (bits % 16) vec = false;
+    }
+    if (vec) {
+        const int chunks = C / 4;
+        int L = 1;
+        while (L < 64 && L < chunks) L <<= 1;
+        const int nch = cdiv(chunks, L);
+        const int64_t threads = tokens * L;
+        dim3 grid((unsigned)cdiv64(threads, 256), nprob);
+        if (nch == 1) hipLaunchKernelGGL(layernorm_vec_kernel<1>, grid, dim3(256), 0, stream, batch, tokens, C, L, elu);
+        else if (nch == 2) hipLaunchKernelGGL(layernorm_vec_kernel<2>, grid, dim3(256), 0, stream, batch, tokens, C, L, elu);
+        else hipLaunchKernelGGL(layernorm_vec_kernel<4>, grid, dim3(256), 0, stream, batch, tokens, C, L, elu);
+        return check_launch("layernorm_vec");
+    }
     int L = 1;
     while (L < 64 && L * 4 < C) L <<= 1;
     const int64_t threads = tokens * L;

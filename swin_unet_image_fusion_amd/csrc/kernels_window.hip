@@ -537,137 +537,163 @@ struct AttnMfmaArgs {
 };
 
 template <int D>
-__global__ __launch_bounds__(256) void attn_core_mfma_kernel(AttnMfmaArgs a) {
-    constexpr int T = 64, WH = 8, WW = 8, HG = 4, QS = cround(D, 8), QKS = cceil(D, 16), MT = cceil(D, 32), TW = 2 * WW - 1;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* qimg = reinterpret_cast<bf16*>(smem);                 // [HG][64][QS]
-    bf16* kimg = qimg + HG * T * QS;
-    f16* vt = reinterpret_cast<f16*>(kimg + HG * T * QS);       // [HG][D][64]
-    float* biasm = reinterpret_cast<float*>(vt + HG * D * T);   // [64 keys][64 queries], exp2 units
-    float* tab = biasm + T * T;
+__global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
+    // one workgroup = (window, head, stream); wave = 32-query block
+    constexpr int T = 64, WH = 8, WW = 8, QS = cround(D, 8), QKS = cceil(D, 16), MT = cceil(D, 32), TW = 2 * WW - 1, VRS = T + 8;
+    constexpr int VEC = (D % 4 == 0) ? 4 : ((D % 2 == 0) ? 2 : 1);   // floats per global load of a head's channel run
+    constexpr int CPT = D / VEC, NCHUNK = T * CPT, NIT = cceil(NCHUNK, 128);
+    __shared__ __attribute__((aligned(16))) bf16 qimg[T * QS];
+    __shared__ __attribute__((aligned(16))) bf16 kimg[T * QS];
+    __shared__ __attribute__((aligned(16))) f16 vt[D * VRS];
+    __shared__ float tab[(2 * WH - 1) * TW];
 
-    const int p = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int p = blockIdx.z, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, qb = tid >> 6;
     const int H = a.H, W = a.W, nwx = W / WW, nwy = H / WH;
-    const int win = blockIdx.x, hg = blockIdx.y;
+    const int win = blockIdx.x;
     const int b = win / (nwx * nwy), wrem = win % (nwx * nwy), wy = wrem / nwx, wx = wrem % nwx;
     const int sh = a.shift ? WH / 2 : 0, sw = a.shift ? WW / 2 : 0;
     const float qscale = kLog2e / sqrtf((float)D);
 
-    for (int i = tid; i < (2 * WH - 1) * TW; i += 256) tab[i] = a.table[p][i];
-    // Q / K / V of this head group -> LDS images
-    for (int e = tid; e < T * HG * QS; e += 256) {
-        const int c = e % QS, hl = (e / QS) % HG, tok = e / (QS * HG);
-        const int head = hg * HG + hl;
-        float qv = 0.f, kv = 0.f;
-        if (c < D && head < a.heads) {
+    for (int i = tid; i < (2 * WH - 1) * TW; i += 128) tab[i] = a.table[p][i] * kLog2e;
+    if constexpr (QS != D) {   // K padding of the Q / K rows
+        for (int i = tid; i < T * (QS - D); i += 128) {
+            const int tok = i / (QS - D), c = D + i % (QS - D);
+            qimg[tok * QS + c] = (bf16)0.f;
+            kimg[tok * QS + c] = (bf16)0.f;
+        }
+    }
+    // Q / K / V of this head -> LDS images; all loads of a thread are issued before the first conversion
+    float qv[NIT][VEC], kv[NIT][VEC], vv[NIT][VEC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * 128;
+        if (e < NCHUNK) {
+            const int tok = e / CPT, c0 = (e % CPT) * VEC;
             const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
             const int64_t t = ((int64_t)b * H + oy) * W + ox;
-            qv = a.Q[p][t * a.ldq + head * D + c] * qscale;
-            kv = a.K[p][t * a.ldk + head * D + c];
-            vt[(hl * D + c) * T + vt_pos(tok)] = (f16)a.V[p][t * a.ldv + head * D + c];
+            const float* qp = a.Q[p] + t * a.ldq + head * D + c0;
+            const float* kp = a.K[p] + t * a.ldk + head * D + c0;
+            const float* vp = a.V[p] + t * a.ldv + head * D + c0;
+            if constexpr (VEC == 4) {
+                const float4 x = *reinterpret_cast<const float4*>(qp), y = *reinterpret_cast<const float4*>(kp), z = *reinterpret_cast<const float4*>(vp);
+                qv[it][0] = x.x; qv[it][1] = x.y; qv[it][2] = x.z; qv[it][3] = x.w;
+                kv[it][0] = y.x; kv[it][1] = y.y; kv[it][2] = y.z; kv[it][3] = y.w;
+                vv[it][0] = z.x; vv[it][1] = z.y; vv[it][2] = z.z; vv[it][3] = z.w;
+            } else if constexpr (VEC == 2) {
+                const float2 x = *reinterpret_cast<const float2*>(qp), y = *reinterpret_cast<const float2*>(kp), z = *reinterpret_cast<const float2*>(vp);
+                qv[it][0] = x.x; qv[it][1] = x.y; kv[it][0] = y.x; kv[it][1] = y.y; vv[it][0] = z.x; vv[it][1] = z.y;
+            } else {
+                qv[it][0] = *qp; kv[it][0] = *kp; vv[it][0] = *vp;
+            }
         }
-        qimg[(hl * T + tok) * QS + c] = (bf16)qv;
-        kimg[(hl * T + tok) * QS + c] = (bf16)kv;
     }
-    __syncthreads();   // table visible
-    const bool last_row = a.shift && wy == nwy - 1, last_col = a.shift && wx == nwx - 1;
-    for (int i = tid; i < T * T; i += 256) {
-        const int key = i / T, q = i % T;
-        const int ky = key / WW, kx = key % WW, qy = q / WW, qx = q % WW;
-        float v = tab[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
-        const bool my = last_row && ((ky >= WH - WH / 2) != (qy >= WH - WH / 2));
-        const bool mx = last_col && ((kx >= WW - WW / 2) != (qx >= WW - WW / 2));
-        if (my || mx) v = -1e10f;
-        biasm[i] = v * kLog2e;
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * 128;
+        if (e < NCHUNK) {
+            const int tok = e / CPT, c0 = (e % CPT) * VEC;
+            const int vp = vt_pos(tok);
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                qimg[tok * QS + c0 + j] = (bf16)(qv[it][j] * qscale);
+                kimg[tok * QS + c0 + j] = (bf16)kv[it][j];
+                vt[(c0 + j) * VRS + vp] = (f16)vv[it][j];
+            }
+        }
     }
     __syncthreads();
 
-    const int hl = wave, head = hg * HG + hl;
-    if (head >= a.heads) return;
     const int r = lane & 31, hf = lane >> 5;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
-    for (int qb = 0; qb < 2; ++qb) {
-        const bf16* qrow = qimg + (hl * T + 32 * qb + r) * QS;
-        f32x16 acc[2];
+    const int q = 32 * qb + r, qy = q >> 3, qx = q & 7;
+    const bool last_row = a.shift && wy == nwy - 1, last_col = a.shift && wx == nwx - 1;
+    const bf16* qrow = qimg + q * QS;
+    f32x16 acc[2];
+    // accumulator init = relative-position bias (+ shift mask), exp2 units.  Register i of key tile kt is key row
+    // ky = 4*kt + (i>>2), column kx = (i&3) + 4*hf  (C/D map of the 32x32 MFMA with 8 keys per window row).
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt) {
+    for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) acc[kt][i] = biasm[(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hf) * T + 32 * qb + r];
-            const bf16* krow = kimg + (hl * T + 32 * kt + r) * QS;
+        for (int i = 0; i < 16; ++i) {
+            const int ky = 4 * kt + (i >> 2), kx = (i & 3) + 4 * hf;
+            float v = tab[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
+            const bool my = last_row && ((ky >= WH - WH / 2) != (qy >= WH - WH / 2));
+            const bool mx = last_col && ((kx >= WW - WW / 2) != (qx >= WW - WW / 2));
+            acc[kt][i] = (my || mx) ? -1e10f * kLog2e : v;
+        }
 #pragma unroll
-            for (int ks = 0; ks < QKS; ++ks) {
-                bf16x8 ka = zero8, qv = zero8;
-                if (ks * 16 + 8 * hf + 8 <= QS) {
-                    ka = *reinterpret_cast<const bf16x8*>(krow + ks * 16 + 8 * hf);
-                    qv = *reinterpret_cast<const bf16x8*>(qrow + ks * 16 + 8 * hf);
-                }
-                acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qv, acc[kt], 0, 0, 0);
+    for (int kt = 0; kt < 2; ++kt) {
+        const bf16* krow = kimg + (32 * kt + r) * QS;
+#pragma unroll
+        for (int ks = 0; ks < QKS; ++ks) {
+            bf16x8 ka = zero8, qf = zero8;
+            if (ks * 16 + 8 * hf + 8 <= QS) {
+                ka = *reinterpret_cast<const bf16x8*>(krow + ks * 16 + 8 * hf);
+                qf = *reinterpret_cast<const bf16x8*>(qrow + ks * 16 + 8 * hf);
+            }
+            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf, acc[kt], 0, 0, 0);
+        }
+    }
+    float mx = max3f(acc[0][0], acc[0][1], acc[1][0]);
+    mx = max3f(mx, acc[1][1], acc[0][2]);
+#pragma unroll
+    for (int i = 3; i < 16; i += 2) mx = max3f(mx, acc[0][i], acc[0][i + 1 < 16 ? i + 1 : i]);
+#pragma unroll
+    for (int i = 2; i < 16; i += 2) mx = max3f(mx, acc[1][i], acc[1][i + 1]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float l = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float pv = __builtin_amdgcn_exp2f(acc[kt][i] - mx);
+            acc[kt][i] = pv;
+            l += pv;
+        }
+    l += __shfl_xor(l, 32);
+    f32x16 o[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[mt][i] = 0.f;
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (f16)acc[kt][8 * s2 + e];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                int c = mt * 32 + r;
+                c = c < D ? c : D - 1;
+                const f16x8 va = *reinterpret_cast<const f16x8*>(vt + c * VRS + kt * 32 + s2 * 16 + 8 * hf);
+                o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pf, o[mt], 0, 0, 0);
             }
         }
-        float mx = acc[0][0];
+    const float inv = 1.0f / l;
+    const int oy = (wy * WH + q / WW + sh) % H, ox = (wx * WW + q % WW + sw) % W;
+    float* orow = a.O[p] + (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
 #pragma unroll
-        for (int i = 1; i < 16; ++i) mx = fmaxf(mx, acc[0][i]);
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) mx = fmaxf(mx, acc[1][i]);
-        mx = fmaxf(mx, __shfl_xor(mx, 32));
-        float l = 0.f;
+        for (int i = 0; i < 16; i += 4) {
+            // registers i..i+3 of a lane are 4 consecutive channels of its query's token: one 16-byte store when aligned
+            const int c = mt * 32 + 8 * (i >> 2) + 4 * hf;
+            if constexpr (D % 4 == 0) {
+                if (c < D) *reinterpret_cast<float4*>(orow + c) = make_float4(o[mt][i] * inv, o[mt][i + 1] * inv, o[mt][i + 2] * inv, o[mt][i + 3] * inv);
+            } else {
 #pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const float pv = __builtin_amdgcn_exp2f(acc[kt][i] - mx);
-                acc[kt][i] = pv;
-                l += pv;
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < D) orow[c + j] = o[mt][i + j] * inv;
             }
-        l += __shfl_xor(l, 32);
-        f32x16 o[MT];
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) o[mt][i] = 0.f;
-#pragma unroll
-        for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2) {
-                f16x8 pf;
-#pragma unroll
-                for (int e = 0; e < 8; ++e) pf[e] = (f16)acc[kt][8 * s2 + e];
-#pragma unroll
-                for (int mt = 0; mt < MT; ++mt) {
-                    int c = mt * 32 + r;
-                    c = c < D ? c : D - 1;
-                    const f16x8 va = *reinterpret_cast<const f16x8*>(vt + (hl * D + c) * T + kt * 32 + s2 * 16 + 8 * hf);
-                    o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pf, o[mt], 0, 0, 0);
-                }
-            }
-        const float inv = 1.0f / l;
-        const int tok = 32 * qb + r;
-        const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
-        float* orow = a.O[p] + (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
-#pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                const int c = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
-                if (c < D) orow[c] = o[mt][i] * inv;
-            }
-    }
+        }
 }
 
 template <int D>
 static int launch_attn_mfma_t(const AttnMfmaArgs& a, int nprob, hipStream_t stream) {
-    constexpr int QS = cround(D, 8);
-    constexpr size_t lds = size_t(2) * 4 * 64 * QS * 2 + size_t(4) * D * 64 * 2 + 64 * 64 * 4 + 15 * 15 * 4;
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    if (lds > 64 * 1024)
-        std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_mfma_kernel<D>),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        });
-    if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(attn_core_mfma): %s", hipGetErrorString(attr_err));
     const int nwin = a.B * (a.H / 8) * (a.W / 8);
-    hipLaunchKernelGGL((attn_core_mfma_kernel<D>), dim3(nwin, cceil(a.heads, 4), nprob), dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((attn_core_mfma_kernel<D>), dim3(nwin, a.heads, nprob), dim3(128), 0, stream, a);
     return check_launch("attn_core_mfma");
 }
 
