@@ -39,6 +39,10 @@ constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
 template <int C_, int HID_>
 struct Geo {
     static constexpr int C = C_, HID = HID_, T = 64, WH = 8, WW = 8, HEADS = 8, D = C / 8;
+    // Are both streams' weight sections LDS-resident?  They are at C=24 (2 x 35 KB).  From C=48 on they do not fit
+    // next to the window tile (2 x 135 KB); the kernel then reads weight fragments from L2 (all workgroups share
+    // the same lines; a wave's fragment loads are address-independent and issue ahead of their MFMAs).
+    static constexpr bool WLDS = C <= 24;
     static_assert(C % 8 == 0, "8 heads of C/8 channels");
     static constexpr int KC = cround(C, 32), KH = cround(HID, 32);      // K extents padded to the MFMA k-step
     static constexpr int LDC = KC + 8;                                  // row stride (bf16) of the token-major images: odd multiple of 16 B -> conflict-free b128 reads
@@ -70,8 +74,8 @@ struct Geo {
     static constexpr size_t l_vt = l_k + img;                             // fp16 [2][C] x VRS: V^T, keys in MFMA k order
     static constexpr size_t l_mask = l_vt + size_t(2) * C * VRS * 2;      // [8 heads][NKS][2 lane halves] x 16 B: channel masks of a head
     static constexpr size_t l_w = (l_mask + size_t(HEADS) * NKS * 2 * 16 + 15) / 16 * 16;   // the two streams' weight sections
-    static constexpr size_t l_total = l_w + 2 * wsec;
-    static_assert(l_total <= 160 * 1024, "window tile + weights exceed the 160 KiB LDS of a CU");
+    static constexpr size_t l_total = l_w + (WLDS ? 2 * wsec : 0);
+    static_assert(l_total <= 160 * 1024, "window tile (+ weights) exceed the 160 KiB LDS of a CU");
 };
 
 struct WinArgs {
@@ -217,17 +221,19 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
     const int nwin = args.B * nwx * nwy;
     const int sh = args.shift ? G::WH / 2 : 0, sw = args.shift ? G::WW / 2 : 0;
 
-    auto wsec = [&](int s) { return smem + G::l_w + s * G::wsec; };
+    auto wsec = [&](int s) -> const char* { return G::WLDS ? smem + G::l_w + s * G::wsec : args.packed[s]; };
     auto wmat = [&](int s, size_t off) { return reinterpret_cast<const bf16*>(wsec(s) + off); };
     auto wvec = [&](int s) { return reinterpret_cast<const float*>(wsec(s) + G::p_vec); };
 
     // ---- once per workgroup: weights -> LDS, zero the images (the K padding of Q / K rows is never written
     //      again and must read as exact zeros), build the per-head channel masks ----
     {
-        constexpr int W16 = G::wsec / 16;
-        for (int i = tid; i < 2 * W16; i += 512) {
-            const int s = i / W16, e = i % W16;
-            reinterpret_cast<uint4*>(wsec(s))[e] = reinterpret_cast<const uint4*>(args.packed[s])[e];
+        if constexpr (G::WLDS) {
+            constexpr int W16 = G::wsec / 16;
+            for (int i = tid; i < 2 * W16; i += 512) {
+                const int s = i / W16, e = i % W16;
+                reinterpret_cast<uint4*>(smem + G::l_w + s * G::wsec)[e] = reinterpret_cast<const uint4*>(args.packed[s])[e];
+            }
         }
         constexpr int Z16 = (G::l_vt - G::l_ahi) / 16;
         uint4* z = reinterpret_cast<uint4*>(smem + G::l_ahi);
@@ -295,7 +301,8 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
             Frag<KS> x;
             load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
             const int kvs = args.cross ? 1 - ws : ws;
-#pragma unroll
+            constexpr int NT_UNROLL = G::WLDS ? G::NTC : 1;   // see HC_UNROLL
+#pragma unroll NT_UNROLL
             for (int nt = 0; nt < G::NTC; ++nt) {
                 const int ch4 = nt * 16 + 4 * g;           // this lane's 4 output channels (transposed tiles)
                 const int wrow = nt * 16 + r16 < C ? nt * 16 + r16 : 0;
@@ -437,7 +444,8 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         {
             Frag<KS> x;
             load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
-#pragma unroll
+            constexpr int NT_UNROLL = G::WLDS ? G::NTC : 1;
+#pragma unroll NT_UNROLL
             for (int nt = 0; nt < G::NTC; ++nt) {
                 const int ch4 = nt * 16 + 4 * g;
                 Frag<KS> wp;
@@ -471,7 +479,8 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
             // the next window rewrite them, K padding included)
             bf16* hb_hi[2] = {my_ahi, qimg + (ws * T + wm * 16) * LDC};
             bf16* hb_lo[2] = {my_alo, kimg + ((args.cross ? 1 - ws : ws) * T + wm * 16) * LDC};
-#pragma unroll
+            constexpr int HC_UNROLL = G::WLDS ? G::KH / 32 : 2;   // L2-sourced weights: full unrolling hoists every fragment load and spills
+#pragma unroll HC_UNROLL
             for (int hc = 0; hc < G::KH / 32; ++hc) {
                 bf16* hhi = hb_hi[hc & 1];
                 bf16* hlo = hb_lo[hc & 1];
@@ -795,7 +804,7 @@ __global__ __launch_bounds__(256) void pack_block_kernel(PackArgs a) {
 // ------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------
-#define SWF_WINDOW_SHAPES(X) X(24, 96) X(24, 4)
+#define SWF_WINDOW_SHAPES(X) X(24, 96) X(24, 4) X(48, 192) X(48, 96)
 
 // one persistent workgroup per CU (its LDS footprint admits exactly one)
 static int num_cus() {
