@@ -34,6 +34,12 @@ inline int launch_gemm(int fast, const GemmBatch& batch, int nprob, int M, int N
                 : launch_gemm_f32(batch, nprob, M, N, K, lda, ldo, act, stream);
 }
 
+// LayerNorm-prologue GEMM (fast tier): out[M][N] = act(LN(x[M][C]; gamma, beta) . W[N][C]^T + bias)
+struct LnGemmProb { const float* x; const float* gamma; const float* beta; const float* W; const float* bias; float* out; };
+struct LnGemmBatch { LnGemmProb p[kMaxProb]; };
+bool lngemm_supported(int C);
+int launch_lngemm_bf16x3(const LnGemmBatch& batch, int nprob, int M, int N, int C, int act, hipStream_t stream);
+
 struct LnProb { const float* in; float* out; const float* gamma; const float* beta; };
 struct LnBatch { LnProb p[2]; };
 // LayerNorm over the last dim (eps 1e-5, biased variance), optional ELU on the result.

@@ -312,6 +312,181 @@ int launch_gemm_bf16x3(const GemmBatch& batch, int nprob, int M, int N, int K, i
 }
 
 // ------------------------------------------------------------------------------------------
+// LayerNorm-prologue GEMM (fast tier): out = act(LN(x) . W^T + bias).  K = C is the LayerNorm width, so a
+// workgroup's 64-row A tile holds complete token rows: it is loaded once, normalised in registers, split into
+// bf16 hi / lo and kept RESIDENT in LDS for every column tile the workgroup walks; only W streams (64 x 64
+// slabs, split on the fly, next slab's loads in flight during the MFMAs).  Replaces a LayerNorm launch + the
+// normalised-activation round trip + a GEMM.  Output tiles are computed transposed (W rows as the MFMA A
+// operand) so a lane owns 4 consecutive output columns of one row: 16-byte stores.
+// ------------------------------------------------------------------------------------------
+constexpr int LBK = 64, LLD = LBK + 8;
+
+__global__ __launch_bounds__(256) void lngemm_bf16x3_kernel(LnGemmBatch batch, int M, int N, int C, int act, int ct_per_wg) {
+    extern __shared__ __attribute__((aligned(16))) char lsm[];
+    const LnGemmProb pr = batch.p[blockIdx.z];
+    const int KP = (C + 31) / 32 * 32;          // K padded to the MFMA k-step
+    const int ALD = KP + 8;                     // A image row stride (bf16): odd multiple of 16 B
+    bf16_t* a_hi = reinterpret_cast<bf16_t*>(lsm);
+    bf16_t* a_lo = a_hi + GBM * ALD;
+    bf16_t* w_hi = a_lo + GBM * ALD;            // [64][LLD] slab
+    bf16_t* w_lo = w_hi + GBN * LLD;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int brow = blockIdx.x * GBM;
+
+    // ---- prologue: LayerNorm of 64 rows, 4 lanes per row, each lane a strided set of float4 chunks ----
+    {
+        const int row = tid >> 2, part = tid & 3;
+        const bool live = brow + row < M;
+        const float4* x = reinterpret_cast<const float4*>(pr.x + (int64_t)(live ? brow + row : 0) * C);
+        const int chunks = C >> 2;               // C % 4 == 0 (checked by the launcher)
+        float sum = 0.f;
+        for (int ch = part; ch < chunks; ch += 4) { const float4 v = x[ch]; sum += (v.x + v.y) + (v.z + v.w); }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const float mean = sum / (float)C;
+        float var = 0.f;
+        for (int ch = part; ch < chunks; ch += 4) {
+            const float4 v = x[ch];
+            const float a = v.x - mean, b = v.y - mean, c = v.z - mean, d = v.w - mean;
+            var += (a * a + b * b) + (c * c + d * d);
+        }
+        var += __shfl_xor(var, 1);
+        var += __shfl_xor(var, 2);
+        const float rstd = 1.0f / sqrtf(var / (float)C + 1e-5f);
+        const float4* g4 = reinterpret_cast<const float4*>(pr.gamma);
+        const float4* b4 = reinterpret_cast<const float4*>(pr.beta);
+        for (int ch = part; ch < (KP >> 2); ch += 4) {
+            bf16x4_t h = {0, 0, 0, 0}, l = {0, 0, 0, 0};
+            if (live && ch < chunks) {
+                const float4 v = x[ch], gg = g4[ch], bb = b4[ch];
+                const float4 n = make_float4((v.x - mean) * rstd * gg.x + bb.x, (v.y - mean) * rstd * gg.y + bb.y,
+                                             (v.z - mean) * rstd * gg.z + bb.z, (v.w - mean) * rstd * gg.w + bb.w);
+                split4(n, h, l);
+            }
+            *reinterpret_cast<bf16x4_t*>(a_hi + row * ALD + ch * 4) = h;
+            *reinterpret_cast<bf16x4_t*>(a_lo + row * ALD + ch * 4) = l;
+        }
+    }
+
+    // ---- column tiles: W slabs of 64 output columns x 64 k ----
+    const int wr = wave >> 1, wc = wave & 1;     // wave -> 32 columns (wr) x 32 rows (wc) of the transposed tile
+    const int fr = lane & 15, fq = lane >> 4;
+    const int lr = tid >> 2, lk = (tid & 3) * 16;   // staging: W row lr, 16 consecutive k
+    const int ncol_tiles = (N + GBN - 1) / GBN;
+    for (int ct = 0; ct < ct_per_wg; ++ct) {
+        const int ctile = blockIdx.y * ct_per_wg + ct;
+        if (ctile >= ncol_tiles) break;
+        const int bcol = ctile * GBN;
+        const bool w_in = bcol + lr < N;
+        const float* wrow = pr.W + (int64_t)(w_in ? bcol + lr : 0) * C;
+        f32x4 acc[2][2];
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n) acc[m][n] = f32x4{0.f, 0.f, 0.f, 0.f};
+        float4 wv[4];
+        auto wload = [&](int k0) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const int k = k0 + lk + 4 * i;
+                wv[i] = (w_in && k < C) ? *reinterpret_cast<const float4*>(wrow + k) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        };
+        wload(0);
+        for (int k0 = 0; k0 < KP; k0 += LBK) {
+            __syncthreads();   // previous slab's fragment reads (and, first time, the A image writes) are done
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                bf16x4_t h, l;
+                split4(wv[i], h, l);
+                *reinterpret_cast<bf16x4_t*>(w_hi + lr * LLD + lk + 4 * i) = h;
+                *reinterpret_cast<bf16x4_t*>(w_lo + lr * LLD + lk + 4 * i) = l;
+            }
+            __syncthreads();
+            if (k0 + LBK < KP) wload(k0 + LBK);
+#pragma unroll
+            for (int ks = 0; ks < LBK / 32; ++ks) {
+                if (k0 + ks * 32 >= KP) break;
+                bf16x8_t wh[2], wl[2], ah[2], al[2];
+#pragma unroll
+                for (int m = 0; m < 2; ++m) {   // MFMA A operand = W rows (output columns)
+                    wh[m] = *reinterpret_cast<const bf16x8_t*>(w_hi + (wr * 32 + m * 16 + fr) * LLD + ks * 32 + 8 * fq);
+                    wl[m] = *reinterpret_cast<const bf16x8_t*>(w_lo + (wr * 32 + m * 16 + fr) * LLD + ks * 32 + 8 * fq);
+                }
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {   // MFMA B operand = activation rows
+                    ah[n] = *reinterpret_cast<const bf16x8_t*>(a_hi + (wc * 32 + n * 16 + fr) * ALD + k0 + ks * 32 + 8 * fq);
+                    al[n] = *reinterpret_cast<const bf16x8_t*>(a_lo + (wc * 32 + n * 16 + fr) * ALD + k0 + ks * 32 + 8 * fq);
+                }
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+#pragma unroll
+                    for (int n = 0; n < 2; ++n) {
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[m], ah[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m], al[n], acc[m][n], 0, 0, 0);
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[m], ah[n], acc[m][n], 0, 0, 0);
+                    }
+            }
+        }
+        // acc[m][n][j]: output column bcol + wr*32 + m*16 + 4*fq + j, row brow + wc*32 + n*16 + fr
+#pragma unroll
+        for (int m = 0; m < 2; ++m) {
+            const int col = bcol + wr * 32 + m * 16 + 4 * fq;
+            if (col >= N) continue;
+            float bv[4] = {0.f, 0.f, 0.f, 0.f};
+            if (pr.bias) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) if (col + j < N) bv[j] = pr.bias[col + j];
+            }
+#pragma unroll
+            for (int n = 0; n < 2; ++n) {
+                const int row = brow + wc * 32 + n * 16 + fr;
+                if (row >= M) continue;
+                float v[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { v[j] = acc[m][n][j] + bv[j]; if (act == 1) v[j] = elu1(v[j]); }
+                float* o = pr.out + (int64_t)row * N + col;
+                if (col + 3 < N && (N & 3) == 0) *reinterpret_cast<float4*>(o) = make_float4(v[0], v[1], v[2], v[3]);
+                else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) if (col + j < N) o[j] = v[j];
+                }
+            }
+        }
+    }
+}
+
+// Worth it only while the per-workgroup LayerNorm prologue is small next to its GEMM work: measured on MI355X at
+// B=16, the C=96 block gains 13 us, C=192 loses 20 us and C=384 loses 50 us (few column tiles per A tile).
+bool lngemm_supported(int C) { return C % 4 == 0 && C >= 4 && C <= 128; }
+
+int launch_lngemm_bf16x3(const LnGemmBatch& batch, int nprob, int M, int N, int C, int act, hipStream_t stream) {
+    if (M <= 0 || N <= 0 || C <= 0) return fail(SWF_ERR_BAD_SHAPE, "lngemm: empty problem");
+    if (!lngemm_supported(C)) return fail(SWF_ERR_UNSUPPORTED, "lngemm: C=%d", C);
+    for (int i = 0; i < nprob; ++i) {
+        const uintptr_t bits = reinterpret_cast<uintptr_t>(batch.p[i].x) | reinterpret_cast<uintptr_t>(batch.p[i].W) |
+                               reinterpret_cast<uintptr_t>(batch.p[i].gamma) | reinterpret_cast<uintptr_t>(batch.p[i].beta) |
+                               reinterpret_cast<uintptr_t>(batch.p[i].out);
+        if (bits % 16) return fail(SWF_ERR_UNSUPPORTED, "lngemm: operands must be 16-byte aligned");
+    }
+    const int KP = (C + 31) / 32 * 32;
+    const size_t lds = (size_t)2 * GBM * (KP + 8) * 2 + (size_t)2 * GBN * LLD * 2;
+    static size_t lds_cap = 0;
+    if (lds > 64 * 1024 && lds > lds_cap) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&lngemm_bf16x3_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(lngemm): %s", hipGetErrorString(e));
+        lds_cap = 160 * 1024;
+    }
+    // column tiles per workgroup: walk several while the grid still oversubscribes the chip (amortises the prologue)
+    const int row_tiles = cdiv(M, GBM), col_tiles = cdiv(N, GBN);
+    int ct = 1;
+    while (ct < col_tiles && (int64_t)row_tiles * cdiv(col_tiles, ct * 2) * nprob >= 1024) ct *= 2;
+    dim3 grid(row_tiles, cdiv(col_tiles, ct), nprob);
+    hipLaunchKernelGGL(lngemm_bf16x3_kernel, grid, dim3(256), lds, stream, batch, M, N, C, act, ct);
+    return check_launch("lngemm_bf16x3");
+}
+
+// ------------------------------------------------------------------------------------------
 // LayerNorm over C per token.  L lanes (power of two) cooperate on a token.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void layernorm_kernel(LnBatch batch, int64_t tokens, int C, int L, int elu) {

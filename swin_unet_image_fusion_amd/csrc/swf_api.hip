@@ -45,7 +45,10 @@ static int64_t splitk_need(int K, int64_t nprob_m_n) {
 static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn_params* const* prm,
                              const float* const* qsrc, const float* const* ksrc, const float* const* vsrc,
                              const float* const* residual, float* const* out, int B, int H, int W, Carver& ws,
-                             hipStream_t stream, int fast = 0) {
+                             hipStream_t stream, int fast = 0, const swf_norm* const* qnorm = nullptr,
+                             const swf_norm* const* kvnorm = nullptr) {
+    // qnorm / kvnorm non-null: q/k/v sources are PRE-LayerNorm tensors and the projections run with the
+    // LayerNorm prologue (fast tier only)
     const int64_t N = (int64_t)B * H * W;
     const int C = d.channels, HD = d.heads * d.head_dim;
     float* qkv[2][3] = {{nullptr, nullptr, nullptr}, {nullptr, nullptr, nullptr}};
@@ -64,7 +67,18 @@ static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn
         const float* src[3] = {qsrc[s], ksrc[s], vsrc[s]};
         for (int i = 0; i < 3; ++i) gb.p[s * 3 + i] = GemmProb{src[i], lin[i]->weight, lin[i]->bias, nullptr, qkv[s][i]};
     }
-    SWF_TRY(launch_gemm(fast, gb, nstream * 3, (int)N, HD, C, C, HD, 0, stream));
+    if (qnorm) {
+        LnGemmBatch lb{};
+        for (int s = 0; s < nstream; ++s) {
+            const swf_linear* lin[3] = {&prm[s]->q, &prm[s]->k, &prm[s]->v};
+            const float* src[3] = {qsrc[s], ksrc[s], vsrc[s]};
+            const swf_norm* nrm[3] = {qnorm[s], kvnorm[s], kvnorm[s]};
+            for (int i = 0; i < 3; ++i) lb.p[s * 3 + i] = LnGemmProb{src[i], nrm[i]->gamma, nrm[i]->beta, lin[i]->weight, lin[i]->bias, qkv[s][i]};
+        }
+        SWF_TRY(launch_lngemm_bf16x3(lb, nstream * 3, (int)N, HD, C, 0, stream));
+    } else {
+        SWF_TRY(launch_gemm(fast, gb, nstream * 3, (int)N, HD, C, C, HD, 0, stream));
+    }
     if (fast && attn_core_mfma_supported(d.win_h, d.win_w, d.head_dim)) {
         const float* qq[2] = {qkv[0][0], qkv[1][0]};
         const float* kk[2] = {qkv[0][1], qkv[1][1]};
@@ -107,19 +121,30 @@ static int attn_halfblock_generic(const swf_block_desc* desc, const swf_block_st
     const int nstream = py ? 2 : 1;
     const int64_t N = (int64_t)B * H * W;
     const int C = desc->attn.channels;
+    const bool cross = desc->cross && nstream == 2;   // single path ignores cross (a002:83)
+    const int fast = desc->precision == SWF_PREC_FAST;
+    const swf_attn_params* prm[2] = {&px->attn, py ? &py->attn : nullptr};
+    const float* res[2] = {x_in, y_in};
+    float* out[2] = {x_out, y_out};
+    if (fast && lngemm_supported(C)) {
+        // LayerNorm folded into the projection GEMMs: K and V of stream s read the OTHER stream's tokens in a
+        // cross block, normalised with that stream's LayerNorm (a004:29-38 then a002:67-82)
+        const float* raw[2] = {x_in, y_in};
+        const swf_norm* nrm[2] = {&px->ln1, py ? &py->ln1 : nullptr};
+        const float* qsrc[2] = {raw[0], raw[1]};
+        const float* kvsrc[2] = {cross ? raw[1] : raw[0], cross ? raw[0] : raw[1]};
+        const swf_norm* kvn[2] = {cross ? nrm[1] : nrm[0], cross ? nrm[0] : nrm[1]};
+        return attention_generic(desc->attn, nstream, prm, qsrc, kvsrc, kvsrc, res, out, B, H, W, ws, stream, fast, nrm, kvn);
+    }
     float* xn[2] = {ws.floats(N * C), nstream == 2 ? ws.floats(N * C) : nullptr};
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "attention half-block workspace too small");
     LnBatch lb{};
     lb.p[0] = LnProb{x_in, xn[0], px->ln1.gamma, px->ln1.beta};
     if (nstream == 2) lb.p[1] = LnProb{y_in, xn[1], py->ln1.gamma, py->ln1.beta};
     SWF_TRY(launch_layernorm(lb, nstream, N, C, 0, stream));
-    const bool cross = desc->cross && nstream == 2;   // single path ignores cross (a002:83)
-    const swf_attn_params* prm[2] = {&px->attn, py ? &py->attn : nullptr};
     const float* qsrc[2] = {xn[0], xn[1]};
     const float* kvsrc[2] = {cross ? xn[1] : xn[0], cross ? xn[0] : xn[1]};
-    const float* res[2] = {x_in, y_in};
-    float* out[2] = {x_out, y_out};
-    return attention_generic(desc->attn, nstream, prm, qsrc, kvsrc, kvsrc, res, out, B, H, W, ws, stream, desc->precision == SWF_PREC_FAST);
+    return attention_generic(desc->attn, nstream, prm, qsrc, kvsrc, kvsrc, res, out, B, H, W, ws, stream, fast);
 }
 
 static int mlp_halfblock_generic(const swf_block_desc* desc, const swf_block_stream_params* px,
@@ -128,26 +153,34 @@ static int mlp_halfblock_generic(const swf_block_desc* desc, const swf_block_str
     const int nstream = py ? 2 : 1;
     const int64_t N = (int64_t)B * H * W;
     const int C = desc->attn.channels, hid = desc->hidden;
-    float* xn[2] = {ws.floats(N * C), nstream == 2 ? ws.floats(N * C) : nullptr};
-    float* hb[2] = {ws.floats(N * hid), nstream == 2 ? ws.floats(N * hid) : nullptr};
     const int fast = desc->precision == SWF_PREC_FAST;
+    const bool fold_ln = fast && lngemm_supported(C);
+    float* xn[2] = {nullptr, nullptr};
+    if (!fold_ln) { xn[0] = ws.floats(N * C); if (nstream == 2) xn[1] = ws.floats(N * C); }
+    float* hb[2] = {ws.floats(N * hid), nstream == 2 ? ws.floats(N * hid) : nullptr};
     const int64_t sk_floats = fast ? std::max(splitk_need(C, nstream * N * hid), splitk_need(hid, nstream * N * C)) : 0;
     float* sk = fast ? ws.floats(sk_floats) : nullptr;
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "MLP half-block workspace too small");
-    LnBatch lb{};
-    lb.p[0] = LnProb{x_in, xn[0], px->ln2.gamma, px->ln2.beta};
-    if (nstream == 2) lb.p[1] = LnProb{y_in, xn[1], py->ln2.gamma, py->ln2.beta};
-    SWF_TRY(launch_layernorm(lb, nstream, N, C, 0, stream));
-    GemmBatch g1{}, g2{};
-    g1.scratch = g2.scratch = sk; g1.scratch_floats = g2.scratch_floats = sk_floats;
     const swf_block_stream_params* pp[2] = {px, py};
     const float* res[2] = {x_in, y_in};
     float* out[2] = {x_out, y_out};
-    for (int s = 0; s < nstream; ++s) {
-        g1.p[s] = GemmProb{xn[s], pp[s]->fc1.weight, pp[s]->fc1.bias, nullptr, hb[s]};
-        g2.p[s] = GemmProb{hb[s], pp[s]->fc2.weight, pp[s]->fc2.bias, res[s], out[s]};
+    GemmBatch g2{};
+    g2.scratch = sk; g2.scratch_floats = sk_floats;
+    for (int s = 0; s < nstream; ++s) g2.p[s] = GemmProb{hb[s], pp[s]->fc2.weight, pp[s]->fc2.bias, res[s], out[s]};
+    if (fold_ln) {
+        LnGemmBatch l1{};
+        for (int s = 0; s < nstream; ++s) l1.p[s] = LnGemmProb{res[s], pp[s]->ln2.gamma, pp[s]->ln2.beta, pp[s]->fc1.weight, pp[s]->fc1.bias, hb[s]};
+        SWF_TRY(launch_lngemm_bf16x3(l1, nstream, (int)N, hid, C, 1, stream));
+    } else {
+        LnBatch lb{};
+        lb.p[0] = LnProb{x_in, xn[0], px->ln2.gamma, px->ln2.beta};
+        if (nstream == 2) lb.p[1] = LnProb{y_in, xn[1], py->ln2.gamma, py->ln2.beta};
+        SWF_TRY(launch_layernorm(lb, nstream, N, C, 0, stream));
+        GemmBatch g1{};
+        g1.scratch = sk; g1.scratch_floats = sk_floats;
+        for (int s = 0; s < nstream; ++s) g1.p[s] = GemmProb{xn[s], pp[s]->fc1.weight, pp[s]->fc1.bias, nullptr, hb[s]};
+        SWF_TRY(launch_gemm(fast, g1, nstream, (int)N, hid, C, C, hid, 1, stream));
     }
-    SWF_TRY(launch_gemm(fast, g1, nstream, (int)N, hid, C, C, hid, 1, stream));
     SWF_TRY(launch_gemm(fast, g2, nstream, (int)N, C, hid, hid, C, 0, stream));
     return SWF_OK;
 }
