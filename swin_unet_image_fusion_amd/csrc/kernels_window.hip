@@ -43,6 +43,7 @@ struct Geo {
     // next to the window tile (2 x 135 KB); the kernel then reads weight fragments from L2 (all workgroups share
     // the same lines; a wave's fragment loads are address-independent and issue ahead of their MFMAs).
     static constexpr bool WLDS = C <= 24;
+    static constexpr int NTK = cround(C, 32) / 16;                       // 16-wide tiles spanning the padded row (residual registers per lane = 4 * NTK)
     static_assert(C % 8 == 0, "8 heads of C/8 channels");
     static constexpr int KC = cround(C, 32), KH = cround(HID, 32);      // K extents padded to the MFMA k-step
     static constexpr int LDC = KC + 8;                                  // row stride (bf16) of the token-major images: odd multiple of 16 B -> conflict-free b128 reads
@@ -66,8 +67,7 @@ struct Geo {
 
     // ---- LDS carve (bytes) ----
     static constexpr size_t img = size_t(2) * T * LDC * 2;                // one token-major bf16 image [2 streams][64][LDC]
-    static constexpr size_t l_resid = 0;                                  // fp32 [2][64][C]: the residual stream
-    static constexpr size_t l_ahi = l_resid + size_t(2) * T * C * 4;      // A image (xn / O / xn2 / hidden chunk), hi and lo parts
+    static constexpr size_t l_ahi = 0;                                    // A image (xn / O / xn2 / hidden chunk), hi and lo parts
     static constexpr size_t l_alo = l_ahi + img;
     static constexpr size_t l_q = l_alo + img;                            // Q (pre-scaled) and K, bf16, all channels of a token in one row
     static constexpr size_t l_k = l_q + img;
@@ -77,6 +77,10 @@ struct Geo {
     static constexpr size_t l_total = l_w + (WLDS ? 2 * wsec : 0);
     static_assert(l_total <= 160 * 1024, "window tile (+ weights) exceed the 160 KiB LDS of a CU");
 };
+
+// L2-sourced weight fragments: stop hipcc from hoisting every iteration's global loads to the loop top (it would
+// spill); a compiler-only fence, no instruction.
+#define SWF_LOAD_FENCE(G_) do { if constexpr (!G_::WLDS) asm volatile("" ::: "memory"); } while (0)
 
 struct WinArgs {
     const float* in[2];
@@ -150,50 +154,42 @@ __device__ __forceinline__ f32x4 mma_bf16x3(const Frag<KSTEPS>& a, const Frag<KS
     return acc;
 }
 
-// LayerNorm of the wave's 16 residual rows into its rows of the split-bf16 A image.  4 lanes per row, lane
-// `part` owns the contiguous columns [part*KC/4, (part+1)*KC/4) of the padded row and writes all of them
-// (zeros beyond C) with 16-byte stores.
+// LayerNorm of the wave's 16 residual rows, straight from registers, into its rows of the split-bf16 A image.
+// Register layout = MFMA output layout of the transposed tiles: lane (r16 = token, g) holds res[nt] = channels
+// nt*16 + 4g .. +3.  A token's channels sit in the 4 lanes with equal r16: two xor-shuffles finish the sums.
+// Columns C..KC-1 (K padding) are written as exact zeros (gamma / beta are stored zero-padded).
 template <typename G>
-__device__ __forceinline__ void layernorm_rows(const float* resid_rows, bf16* ahi_rows, bf16* alo_rows, const float* vec,
-                                               int goff, int boff, int lane) {
-    constexpr int C = G::C, PER = G::KC / 4;
-    static_assert(PER % 8 == 0, "a lane's column run must be whole 16-byte bf16 vectors");
-    const int row = lane >> 2, c0 = (lane & 3) * PER;
-    const float* x = resid_rows + row * C;
-    float v[PER];
+__device__ __forceinline__ void layernorm_regs(const float4 (&res)[G::NTK], bf16* ahi_rows, bf16* alo_rows, const float* vec,
+                                               int goff, int boff, int r16, int g) {
+    constexpr int C = G::C;
     float sum = 0.f;
 #pragma unroll
-    for (int i = 0; i < PER; i += 4) {
-        float4 t = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (c0 + i < C) t = *reinterpret_cast<const float4*>(x + c0 + i);   // C % 4 == 0: a float4 is all in or all out
-        v[i] = t.x; v[i + 1] = t.y; v[i + 2] = t.z; v[i + 3] = t.w;
-        sum += (t.x + t.y) + (t.z + t.w);
-    }
-    sum += __shfl_xor(sum, 1);
-    sum += __shfl_xor(sum, 2);
+    for (int nt = 0; nt < G::NTK; ++nt) sum += (res[nt].x + res[nt].y) + (res[nt].z + res[nt].w);   // padding registers hold zeros
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
     const float mean = sum * (1.0f / C);
     float var = 0.f;
 #pragma unroll
-    for (int i = 0; i < PER; ++i) {
-        const float d = (c0 + i < C) ? v[i] - mean : 0.f;
-        var = fmaf(d, d, var);
+    for (int nt = 0; nt < G::NTK; ++nt) {
+        if (nt * 16 + 4 * g < C) {
+            const float a = res[nt].x - mean, b = res[nt].y - mean, c = res[nt].z - mean, d = res[nt].w - mean;
+            var += (a * a + b * b) + (c * c + d * d);
+        }
     }
-    var += __shfl_xor(var, 1);
-    var += __shfl_xor(var, 2);
+    var += __shfl_xor(var, 16);
+    var += __shfl_xor(var, 32);
     const float rstd = 1.0f / sqrtf(var * (1.0f / C) + 1e-5f);
 #pragma unroll
-    for (int i = 0; i < PER; i += 8) {
-        bf16x8 h, l;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) {
-            const int c = c0 + i + e;
-            // gamma / beta are stored padded to KC with zeros, so padded columns come out as exact zeros
-            const float n = (v[i + e] - mean) * rstd * vec[goff + c] + vec[boff + c];
-            h[e] = (bf16)n;
-            l[e] = (bf16)(n - (float)h[e]);
-        }
-        *reinterpret_cast<bf16x8*>(ahi_rows + row * G::LDC + c0 + i) = h;
-        *reinterpret_cast<bf16x8*>(alo_rows + row * G::LDC + c0 + i) = l;
+    for (int nt = 0; nt < G::NTK; ++nt) {
+        const int c0 = nt * 16 + 4 * g;
+        const float4 gm = *reinterpret_cast<const float4*>(vec + goff + c0);
+        const float4 bt = *reinterpret_cast<const float4*>(vec + boff + c0);
+        const float n[4] = {(res[nt].x - mean) * rstd * gm.x + bt.x, (res[nt].y - mean) * rstd * gm.y + bt.y,
+                            (res[nt].z - mean) * rstd * gm.z + bt.z, (res[nt].w - mean) * rstd * gm.w + bt.w};
+        bf16x4 h, l;
+        split4_bf16(n, h, l);
+        *reinterpret_cast<bf16x4*>(ahi_rows + r16 * G::LDC + c0) = h;
+        *reinterpret_cast<bf16x4*>(alo_rows + r16 * G::LDC + c0) = l;
     }
 }
 
@@ -207,7 +203,6 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
     using G = Geo<C_, HID_>;
     constexpr int C = G::C, D = G::D, T = G::T, LDC = G::LDC, KS = G::KC / 32;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* resid = reinterpret_cast<float*>(smem + G::l_resid);
     bf16* ahi = reinterpret_cast<bf16*>(smem + G::l_ahi);
     bf16* alo = reinterpret_cast<bf16*>(smem + G::l_alo);
     bf16* qimg = reinterpret_cast<bf16*>(smem + G::l_q);
@@ -250,28 +245,26 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         }
     }
 
-    // the wave's own 16 token rows <-> registers (C/4 float4 per token)
+    // the wave's own 16 token rows live in registers for the whole block: lane (r16, g) holds, per 16-channel
+    // tile nt, the 4 channels nt*16 + 4g .. +3 of token wm*16 + r16 (the MFMA output layout of the transposed tiles)
     const int ws = wave >> 2, wm = wave & 3;           // stream and m-tile this wave owns
-    constexpr int V4 = 16 * C / 4, NV = cceil(V4, 64);
-    static_assert(NV <= 4, "prefetch registers");
-    float4 pre0, pre1, pre2, pre3;   // named registers: an array captured by a lambda is demoted to scratch
-    pre0 = pre1 = pre2 = pre3 = make_float4(0.f, 0.f, 0.f, 0.f);
-    auto tile_addr = [&](int win, int i) -> int64_t {
+    const int r16 = lane & 15, g = lane >> 4;
+    constexpr int NTK = G::NTK;
+    float4 res[NTK], pre[NTK];
+    auto token_base = [&](int win) -> int64_t {
         const int b = win / (nwx * nwy), wrem = win % (nwx * nwy);
         const int wy = wrem / nwx, wx = wrem % nwx;
-        const int tok = wm * 16 + i / (C / 4), c4 = i % (C / 4);
+        const int tok = wm * 16 + r16;
         const int oy = (wy * G::WH + tok / G::WW + sh) % H, ox = (wx * G::WW + tok % G::WW + sw) % W;   // roll(-s): read at (y+s)%H
-        return (((int64_t)b * H + oy) * W + ox) * C + c4 * 4;
+        return (((int64_t)b * H + oy) * W + ox) * C;
     };
-#define SWF_PREFETCH(WIN)                                                                                          \
-    do {                                                                                                           \
-        const float* src_ = args.in[ws];                                                                           \
-        if (lane < V4) pre0 = *reinterpret_cast<const float4*>(src_ + tile_addr((WIN), lane));                     \
-        if (NV > 1 && lane + 64 < V4) pre1 = *reinterpret_cast<const float4*>(src_ + tile_addr((WIN), lane + 64));   \
-        if (NV > 2 && lane + 128 < V4) pre2 = *reinterpret_cast<const float4*>(src_ + tile_addr((WIN), lane + 128)); \
-        if (NV > 3 && lane + 192 < V4) pre3 = *reinterpret_cast<const float4*>(src_ + tile_addr((WIN), lane + 192)); \
+#define SWF_PREFETCH(WIN)                                                                                   \
+    do {                                                                                                    \
+        const float* src_ = args.in[ws] + token_base(WIN);                                                  \
+        _Pragma("unroll") for (int nt = 0; nt < NTK; ++nt)                                                  \
+            pre[nt] = (nt * 16 + 4 * g < C) ? *reinterpret_cast<const float4*>(src_ + nt * 16 + 4 * g)      \
+                                            : make_float4(0.f, 0.f, 0.f, 0.f);                              \
     } while (0)
-    float* my_resid = resid + (ws * T + wm * 16) * C;
     bf16* my_ahi = ahi + (ws * T + wm * 16) * LDC;
     bf16* my_alo = alo + (ws * T + wm * 16) * LDC;
 
@@ -281,19 +274,16 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
     f32x16 bfr[2];   // relative-position bias (+mask) of this wave's (stream, query block), S^T layout, exp2 units
     __syncthreads();
 
-    const int r16 = lane & 15, g = lane >> 4;
     for (; win < nwin; win += gridDim.x) {
         const int wrem = win % (nwx * nwy);
         const int wy = wrem / nwx, wx = wrem % nwx;
-        // ---- own rows: registers -> residual; start fetching the next window ----
-        if (lane < V4) *reinterpret_cast<float4*>(my_resid + lane * 4) = pre0;
-        if (NV > 1 && lane + 64 < V4) *reinterpret_cast<float4*>(my_resid + (lane + 64) * 4) = pre1;
-        if (NV > 2 && lane + 128 < V4) *reinterpret_cast<float4*>(my_resid + (lane + 128) * 4) = pre2;
-        if (NV > 3 && lane + 192 < V4) *reinterpret_cast<float4*>(my_resid + (lane + 192) * 4) = pre3;
+        // ---- own rows: prefetched registers become the residual; start fetching the next window ----
+#pragma unroll
+        for (int nt = 0; nt < NTK; ++nt) res[nt] = pre[nt];
         if (win + (int)gridDim.x < nwin) SWF_PREFETCH(win + gridDim.x);
 
         // ---- LN1 -> A image (own rows) ----
-        layernorm_rows<G>(my_resid, my_ahi, my_alo, wvec(ws), G::v_ln1g, G::v_ln1b, lane);
+        layernorm_regs<G>(res, my_ahi, my_alo, wvec(ws), G::v_ln1g, G::v_ln1b, r16, g);
 
         // ---- Q, K, V projections of the own rows.  Q for the own stream; K and V for the stream whose attention
         //      reads these tokens as keys: itself, or the other one in a cross block (a002:67-82) ----
@@ -331,6 +321,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                     f16x4 v4 = {(f16)(av[0] + bv), (f16)(av[1] + bv), (f16)(av[2] + bv), (f16)(av[3] + bv)};
                     *reinterpret_cast<f16x4*>(vt + (kvs * C + chv) * G::VRS + vt_pos(wm * 16 + 4 * g)) = v4;
                 }
+                SWF_LOAD_FENCE(G);
             }
         }
         __syncthreads();   // all Q / K / V^T rows of the window are in place
@@ -354,7 +345,8 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
             f16x8 ones8;
 #pragma unroll
             for (int e = 0; e < 8; ++e) ones8[e] = (f16)1.0f;
-#pragma unroll 2
+            constexpr int HEAD_UNROLL = G::NTK <= 2 ? 2 : 1;   // two heads in flight while the residual registers are few
+#pragma unroll HEAD_UNROLL
             for (int hh = 0; hh < 4; ++hh) {
                 const int head = h0 + hh;
                 // S^T = K . Qmasked^T: K rows carry all channels, the Q fragment is ANDed with the head's channel mask,
@@ -444,9 +436,8 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         {
             Frag<KS> x;
             load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
-            constexpr int NT_UNROLL = G::WLDS ? G::NTC : 1;
-#pragma unroll NT_UNROLL
-            for (int nt = 0; nt < G::NTC; ++nt) {
+#pragma unroll
+            for (int nt = 0; nt < G::NTC; ++nt) {   // fully unrolled: res[] must be indexed statically
                 const int ch4 = nt * 16 + 4 * g;
                 Frag<KS> wp;
                 load_frag<KS, G::KC>(wp, wmat(ws, G::p_wp_hi), wmat(ws, G::p_wp_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g);
@@ -454,16 +445,14 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                 const f32x4 acc = mma_bf16x3<KS>(wp, x, z4);
                 if (ch4 < C) {
                     const float4 bp = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bp + ch4);
-                    float4* rp = reinterpret_cast<float4*>(my_resid + r16 * C + ch4);
-                    float4 rv = *rp;
-                    rv.x += acc[0] + bp.x; rv.y += acc[1] + bp.y; rv.z += acc[2] + bp.z; rv.w += acc[3] + bp.w;
-                    *rp = rv;
+                    res[nt].x += acc[0] + bp.x; res[nt].y += acc[1] + bp.y; res[nt].z += acc[2] + bp.z; res[nt].w += acc[3] + bp.w;
                 }
+                SWF_LOAD_FENCE(G);
             }
         }
 
         // ---- LN2 -> A image (own rows) ----
-        layernorm_rows<G>(my_resid, my_ahi, my_alo, wvec(ws), G::v_ln2g, G::v_ln2b, lane);
+        layernorm_regs<G>(res, my_ahi, my_alo, wvec(ws), G::v_ln2g, G::v_ln2b, r16, g);
 
         // ---- MLP, own rows, walking the hidden dimension in chunks of 32: fc1 + ELU for the chunk -> split-bf16
         //      image over the wave's own A rows (xn2 already sits in registers) -> one k-step of fc2.  The hidden
@@ -501,6 +490,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                     }
                     *reinterpret_cast<bf16x4*>(hhi + r16 * LDC + t2 * 16 + 4 * g) = h4;
                     *reinterpret_cast<bf16x4*>(hlo + r16 * LDC + t2 * 16 + 4 * g) = l4;
+                    SWF_LOAD_FENCE(G);
                 }
                 Frag<1> hfrag;
                 load_frag<1, LDC>(hfrag, hhi, hlo, r16, g);
@@ -509,6 +499,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                     Frag<1> w2;
                     load_frag<1, G::KH>(w2, wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
                     out[nt] = mma_bf16x3<1>(w2, hfrag, out[nt]);
+                    if ((nt & 1) == 1) SWF_LOAD_FENCE(G);
                 }
             }
 #pragma unroll
@@ -516,19 +507,17 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                 const int ch4 = nt * 16 + 4 * g;
                 if (ch4 < C) {
                     const float4 b2 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b2 + ch4);
-                    float4* rp = reinterpret_cast<float4*>(my_resid + r16 * C + ch4);
-                    float4 rv = *rp;
-                    rv.x += out[nt][0] + b2.x; rv.y += out[nt][1] + b2.y; rv.z += out[nt][2] + b2.z; rv.w += out[nt][3] + b2.w;
-                    *rp = rv;
+                    res[nt].x += out[nt][0] + b2.x; res[nt].y += out[nt][1] + b2.y; res[nt].z += out[nt][2] + b2.z; res[nt].w += out[nt][3] + b2.w;
                 }
             }
         }
 
         // ---- store the own rows (un-shift = same index map as the load) ----
+        {
+            float* dst = args.out[ws] + token_base(win);
 #pragma unroll
-        for (int k = 0; k < NV; ++k) {
-            const int i = lane + k * 64;
-            if (i < V4) *reinterpret_cast<float4*>(args.out[ws] + tile_addr(win, i)) = *reinterpret_cast<const float4*>(my_resid + i * 4);
+            for (int nt = 0; nt < NTK; ++nt)
+                if (nt * 16 + 4 * g < C) *reinterpret_cast<float4*>(dst + nt * 16 + 4 * g) = res[nt];
         }
     }
 #undef SWF_PREFETCH
@@ -804,7 +793,7 @@ __global__ __launch_bounds__(256) void pack_block_kernel(PackArgs a) {
 // ------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------
-#define SWF_WINDOW_SHAPES(X) X(24, 96) X(24, 4) X(48, 192) X(48, 96)
+#define SWF_WINDOW_SHAPES(X) X(24, 96) X(24, 4) X(48, 192) X(48, 96) X(96, 384) X(96, 192)
 
 // one persistent workgroup per CU (its LDS footprint admits exactly one)
 static int num_cus() {
