@@ -72,7 +72,8 @@ struct Geo {
     static constexpr size_t l_q = l_alo + img;                            // Q (pre-scaled) and K, bf16, all channels of a token in one row
     static constexpr size_t l_k = l_q + img;
     static constexpr size_t l_vt = l_k + img;                             // fp16 [2][C] x VRS: V^T, keys in MFMA k order
-    static constexpr size_t l_mask = l_vt + size_t(2) * C * VRS * 2;      // [8 heads][NKS][2 lane halves] x 16 B: channel masks of a head
+    static constexpr int ONES_ROW = 2 * C;                                // extra V^T row of 1.0: its product with P^T is the softmax denominator
+    static constexpr size_t l_mask = l_vt + size_t(2 * C + 1) * VRS * 2;  // [8 heads][NKS][2 lane halves] x 16 B: channel masks of a head
     static constexpr size_t l_w = (l_mask + size_t(HEADS) * NKS * 2 * 16 + 15) / 16 * 16;   // the two streams' weight sections
     static constexpr size_t l_total = l_w + (WLDS ? 2 * wsec : 0);
     static_assert(l_total <= 160 * 1024, "window tile (+ weights) exceed the 160 KiB LDS of a CU");
@@ -233,6 +234,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         constexpr int Z16 = (G::l_vt - G::l_ahi) / 16;
         uint4* z = reinterpret_cast<uint4*>(smem + G::l_ahi);
         for (int i = tid; i < Z16; i += 512) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < G::VRS; i += 512) vt[G::ONES_ROW * G::VRS + i] = (f16)1.0f;
         for (int i = tid; i < G::HEADS * G::NKS * 2; i += 512) {
             const int hf = i & 1, ks = (i >> 1) % G::NKS, head = i / (2 * G::NKS);
             unsigned m[4];
@@ -342,9 +344,6 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
             const bf16* qrow = qimg + (s * T + 32 * qb + r) * LDC + 8 * hf;
             const bf16* krow0 = kimg + (s * T + r) * LDC + 8 * hf;
             const bf16* krow1 = krow0 + 32 * LDC;
-            f16x8 ones8;
-#pragma unroll
-            for (int e = 0; e < 8; ++e) ones8[e] = (f16)1.0f;
             constexpr int HEAD_UNROLL = G::NTK <= 2 ? 2 : 1;   // two heads in flight while the residual registers are few
 #pragma unroll HEAD_UNROLL
             for (int hh = 0; hh < 4; ++hh) {
@@ -403,9 +402,11 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                         for (int e = 0; e < 8; ++e) pf[e] = (f16)(kt == 0 ? acc0[8 * s2 + e] : acc1[8 * s2 + e]);
 #pragma unroll
                         for (int mt = 0; mt < G::MT; ++mt) {
+                            // rows beyond the head width read the ones row: row D of the product is then the denominator
+                            // (rows D+1.. are never read back)
                             const int c = mt * 32 + r;
-                            f16x8 va = *reinterpret_cast<const f16x8*>(vt + (s * C + head * D + (c < D ? c : D - 1)) * G::VRS + kt * 32 + s2 * 16 + 8 * hf);
-                            if (c == D) va = ones8;
+                            const int vrow = c < D ? s * C + head * D + c : G::ONES_ROW;
+                            const f16x8 va = *reinterpret_cast<const f16x8*>(vt + vrow * G::VRS + kt * 32 + s2 * 16 + 8 * hf);
                             o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pf, o[mt], 0, 0, 0);
                         }
                     }
@@ -414,7 +415,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                 float l = o[LM][LI];
                 const float l_other = __shfl_xor(l, 32);
                 l = (hf == LH) ? l : l_other;
-                const float inv = 1.0f / l;
+                const float inv = __builtin_amdgcn_rcpf(l);   // v_rcp_f32: 1 ulp, the tier's budget is 1e-3
                 const int tok = 32 * qb + r;
 #pragma unroll
                 for (int mt = 0; mt < G::MT; ++mt)
