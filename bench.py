@@ -67,12 +67,23 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     lib = L.lib()
     desc = blk._desc(precision)
     px, py = blk._stream_params("x"), blk._stream_params("y")
-    ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(C.byref(desc), batch, h, w), dev)
     stream = _stream(dev)
+    nbytes = lib.swf_basic_block_packed_bytes(C.byref(desc))
+    if nbytes:      # fast tier: weights pre-packed once (as the model path does), each launch = exactly the fused kernel
+        packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
+        L.check(lib.swf_basic_block_pack(C.byref(desc), C.byref(px), C.byref(py), packed.data_ptr(), nbytes, stream))
+        kname = "swf::window_block_kernel<24, 96> (one launch = level-0 shifted-window BasicBlock, both streams)"
 
-    def run():
-        L.check(lib.swf_basic_block_fwd(C.byref(desc), C.byref(px), C.byref(py), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy),
-                                        batch, h, w, ws, wsn, stream))
+        def run():
+            L.check(lib.swf_basic_block_fwd_packed(C.byref(desc), packed.data_ptr(), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy),
+                                                   batch, h, w, stream))
+    else:           # exact tier: the unit is a sequence of kernels
+        ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(C.byref(desc), batch, h, w), dev)
+        kname = "level-0 shifted-window BasicBlock unit (swf_basic_block_fwd, exact tier: 7 kernels)"
+
+        def run():
+            L.check(lib.swf_basic_block_fwd(C.byref(desc), C.byref(px), C.byref(py), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy),
+                                            batch, h, w, ws, wsn, stream))
     for _ in range(3):
         run()
     torch.cuda.synchronize()
@@ -98,7 +109,7 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
             traffic = json.load(f).get("hbm_bytes_per_launch")
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
-            "kernel": "level-0 shifted-window BasicBlock launch (swf_basic_block_fwd)",
+            "kernel": kname,
             "ms_per_launch": round(ms, 4), "algorithmic_bytes": alg_bytes, "bytes_per_elem": BYTES_PER_ELEM}
 
 

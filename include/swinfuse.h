@@ -117,6 +117,16 @@ int swf_basic_block_fwd(const swf_block_desc* desc, const swf_block_stream_param
                         void* workspace, size_t workspace_bytes, swf_stream_t stream);
 size_t swf_basic_block_workspace_bytes(const swf_block_desc* desc, int32_t B, int32_t H, int32_t W);
 
+/* Block-level pre-pack for callers that run the same block many times (fast tier): derive the fused kernel's
+ * weight images once into a caller-owned buffer of swf_basic_block_packed_bytes(desc) bytes (0 = this shape has no
+ * fused kernel; use swf_basic_block_fwd), then launch with swf_basic_block_fwd_packed — exactly one kernel. */
+size_t swf_basic_block_packed_bytes(const swf_block_desc* desc);
+int swf_basic_block_pack(const swf_block_desc* desc, const swf_block_stream_params* px,
+                         const swf_block_stream_params* py, void* packed, size_t packed_bytes, swf_stream_t stream);
+int swf_basic_block_fwd_packed(const swf_block_desc* desc, const void* packed,
+                               const float* x_in, const float* y_in, float* x_out, float* y_out,
+                               int32_t B, int32_t H, int32_t W, swf_stream_t stream);
+
 /* SelfAndCrossBlockPair.forward (a012_SelfAndCrossBlockPair.py:70-78): four BasicBlocks in the
  * order self/normal, self/shifted, cross/normal, cross/shifted (a009:90-109).  `desc` gives the
  * shared dims; shift/cross flags inside it are ignored.  px[4], py[4]. */

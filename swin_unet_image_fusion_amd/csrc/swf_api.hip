@@ -602,6 +602,31 @@ int swf_basic_block_fwd(const swf_block_desc* desc, const swf_block_stream_param
     return basic_block_impl(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, workspace, workspace_bytes, as_stream(stream));
 }
 
+size_t swf_basic_block_packed_bytes(const swf_block_desc* desc) {
+    if (!desc || desc->precision != SWF_PREC_FAST) return 0;
+    return 2 * window_block_packed_bytes(*desc);
+}
+
+int swf_basic_block_pack(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                         void* packed, size_t packed_bytes, swf_stream_t stream) {
+    if (!desc) return fail(SWF_ERR_NULL, "desc is NULL");
+    SWF_TRY(check_stream_params(px, "x-stream", true, true));
+    SWF_TRY(check_stream_params(py, "y-stream", true, true));
+    const size_t pb = window_block_packed_bytes(*desc);
+    if (pb == 0 || desc->precision != SWF_PREC_FAST) return fail(SWF_ERR_UNSUPPORTED, "no fused kernel for C=%d hidden=%d", desc->attn.channels, desc->hidden);
+    if (!packed || packed_bytes < 2 * pb) return fail(SWF_ERR_WORKSPACE, "packed buffer too small (need %zu B)", 2 * pb);
+    return pack_window_block(*desc, *px, *py, packed, static_cast<char*>(packed) + pb, as_stream(stream));
+}
+
+int swf_basic_block_fwd_packed(const swf_block_desc* desc, const void* packed, const float* x_in, const float* y_in,
+                               float* x_out, float* y_out, int32_t B, int32_t H, int32_t W, swf_stream_t stream) {
+    if (!desc || !packed || !x_in || !y_in || !x_out || !y_out) return fail(SWF_ERR_NULL, "basic_block_fwd_packed: NULL argument");
+    SWF_TRY(check_attn_desc(&desc->attn, B, H, W));
+    if (!window_block_supported(*desc, B, H, W)) return fail(SWF_ERR_UNSUPPORTED, "no fused kernel for this block shape");
+    const size_t pb = window_block_packed_bytes(*desc);
+    return launch_window_block(*desc, packed, static_cast<const char*>(packed) + pb, x_in, y_in, x_out, y_out, B, H, W, as_stream(stream));
+}
+
 int swf_block_pair4_fwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                         const float* x_in, const float* y_in, float* x_out, float* y_out, int32_t B, int32_t H, int32_t W,
                         void* workspace, size_t workspace_bytes, swf_stream_t stream) {
