@@ -193,7 +193,7 @@ def main():
     if rank == 0:
         total_pairs = args.batch * world * args.steps
         line = {
-            "metric": "fused image-pairs/sec at 256x256, win=8", "value": round(total_pairs / elapsed, 2),
+            "metric": f"fused image-pairs/sec at {args.size}x{args.size}, win={cfg.window_size[0]}", "value": round(total_pairs / elapsed, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "fast" else "f32", "data": "synthetic",

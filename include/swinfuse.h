@@ -232,6 +232,18 @@ int swf_model_forward_packed(const swf_model_desc* desc, const float* arena, con
                              const float* ir, const float* vis, float* out, int32_t B, int32_t H, int32_t W,
                              void* workspace, size_t workspace_bytes, swf_stream_t stream);
 
+/* ---- colour-space steps either side of the model in the reference's inference script ------
+ * a015_dataset.py:73-93 / a017_test.py:68,83-88.  OpenCV's 8-bit fixed-point BGR->YCrCb and float YCrCb->RGB,
+ * restated from its published formulas (cv2 itself is not available to this build). */
+/* bgr [B][H][W][3] uint8 (cv2.imread layout) -> y [B][1][H][W], crcb [B][2][H][W], float32 = uint8/255 */
+int swf_bgr8_to_ycrcb_fwd(const uint8_t* bgr, float* y, float* crcb, int32_t B, int32_t H, int32_t W, swf_stream_t stream);
+/* IR gray uint8 -> float32 / 255 (v2.ToDtype(scale=True), a015:57-60) */
+int swf_gray8_to_unit_fwd(const uint8_t* gray, float* out, int64_t count, swf_stream_t stream);
+/* fused_y [B][1][H][W] (unclamped model output), crcb [B][2][H][W] -> clamp(Y,0,1), YCrCb->RGB:
+ * rgb_f [B][3][H][W] float32 (may be NULL) and/or rgb8 [B][H][W][3] uint8 quantised like torchvision save_image */
+int swf_ycrcb_to_rgb_fwd(const float* fused_y, const float* crcb, float* rgb_f, uint8_t* rgb8,
+                         int32_t B, int32_t H, int32_t W, swf_stream_t stream);
+
 /* ---- misc ------------------------------------------------------------------------------------ */
 int swf_version(void);                     /* major*1000 + minor */
 const char* swf_last_error_string(void);   /* thread-local, never NULL */

@@ -93,6 +93,9 @@ SIGNATURES = {
     "swf_crop_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "swf_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
     "swf_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "swf_bgr8_to_ycrcb_fwd": (C.c_int, [_vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "swf_gray8_to_unit_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "swf_ycrcb_to_rgb_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
     "swf_model_param_count": (_i32, [P(ModelDesc)]),
     "swf_model_param_info": (C.c_int, [P(ModelDesc), _i32, C.c_char_p, _sz, P(_i64), P(_i64)]),
     "swf_model_arena_elems": (_i64, [P(ModelDesc)]),

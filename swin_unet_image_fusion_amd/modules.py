@@ -725,6 +725,15 @@ class MyModel(_FwdAlias, nn.Module):
             self._packed = buf
         return self._packed
 
+    def load_reference_checkpoint(self, path, map_location="cpu") -> dict:
+        """Load a checkpoint written by the reference's training script (a016:243-249:
+        {"model_state", "optimizer_state", "scheduler_state", "current_epoch"}; loaded by a017:50-54).  The aliased
+        3139-key `model_state` loads strictly.  `weights_only=True`: nothing in the file is executed."""
+        state = torch.load(path, map_location=map_location, weights_only=True)
+        model_state = state["model_state"] if isinstance(state, dict) and "model_state" in state else state
+        self.load_state_dict(model_state, strict=True)
+        return {k: v for k, v in state.items() if k != "model_state"} if isinstance(state, dict) else {}
+
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, in_x: Tensor, in_y: Tensor) -> Tensor:
         _check_forward_only(self, in_x, in_y)

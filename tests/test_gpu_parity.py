@@ -287,3 +287,23 @@ def test_model_packed_weights_follow_load_state_dict():
     assert b._packed is None and b._arena is None
     after = b(ir, vis)
     assert torch.equal(after, a.to(DEV)(ir, vis)) and not torch.equal(before, after)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+def test_ragged_640x512_vs_oracle(precision):
+    """The repo's sample images are 640x512: level maps 320x256 ... 20x16 -> the deepest two need
+    reflect padding to a multiple of 8, folded into the merge gather / unmerge scatter index maps; the fused kernels
+    then run on the padded maps."""
+    cfg = CONFIGS["win8"]
+    m = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(m, seed=0, flavor="default")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ir, vis = (torch.from_numpy(a) for a in synthetic_pair(1, 512, 640))
+    ref = O.model_forward(sd, cfg, ir, vis)
+    m.to(DEV)
+    m.precision = precision
+    out = m(ir.to(DEV), vis.to(DEV))
+    if precision == "fp32":
+        _close(out, ref, 5e-5)
+    else:
+        _close(out, ref, TOL_FAST_L2, TOL_FAST_MAX)

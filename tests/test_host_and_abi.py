@@ -132,3 +132,21 @@ def test_product_path_never_imports_the_oracle():
         for fn in files:
             if fn.endswith(".py"):
                 assert not pat.search(open(os.path.join(root, fn)).read()), f"{fn} imports the oracle"
+
+
+def test_reference_format_checkpoint_roundtrip(tmp_path):
+    """A checkpoint in the reference's on-disk format (a016:243-249) loads strictly through weights_only=True."""
+    a = MyModel(**CONFIGS["tiny"].model_kwargs(nn.ELU(inplace=True)))
+    load_recipe_into(a, seed=4, flavor="stress")
+    path = tmp_path / "ckpt.pth"
+    torch.save({"model_state": a.state_dict(), "optimizer_state": {}, "scheduler_state": {}, "current_epoch": 7}, path)
+    b = MyModel(**CONFIGS["tiny"].model_kwargs(nn.ELU(inplace=True)))
+    rest = b.load_reference_checkpoint(str(path))
+    assert rest["current_epoch"] == 7
+    for (ka, va), (kb, vb) in zip(a.state_dict().items(), b.state_dict().items()):
+        assert ka == kb and torch.equal(va, vb)
+    # aliases stay aliases after loading (one storage behind stage_1.other_module.* and auto_path_win_att.*)
+    sd = b.state_dict()
+    k1 = "encoder_list.0.3.self_att_block.normal_window_block.auto_path_win_att.window_attention_x.q_for_heads.weight"
+    k2 = "encoder_list.0.3.self_att_block.normal_window_block.stage_1.other_module.window_attention_x.q_for_heads.weight"
+    assert sd[k1].data_ptr() == sd[k2].data_ptr()
