@@ -27,4 +27,12 @@ int launch_attn_core_mfma(const float* const* Q, const float* const* K, const fl
                           const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
                           int heads, int head_dim, int shift, hipStream_t stream);
 
+// MFMA attention core for 16x16 windows (256 tokens): online softmax over key tiles.  Needs
+// attn_core_mfma16_scratch_floats(nprob) floats of scratch for the per-launch bias (+mask) matrices.
+bool attn_core_mfma16_supported(int wh, int ww, int head_dim);
+size_t attn_core_mfma16_scratch_floats(int nprob);
+int launch_attn_core_mfma16(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
+                            const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
+                            int heads, int head_dim, int shift, float* bias_scratch, hipStream_t stream);
+
 }  // namespace swf

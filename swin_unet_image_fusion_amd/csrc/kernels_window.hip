@@ -697,6 +697,210 @@ static int launch_attn_mfma_t(const AttnMfmaArgs& a, int nprob, hipStream_t stre
     return check_launch("attn_core_mfma");
 }
 
+// ------------------------------------------------------------------------------------------
+// MFMA attention core for 16x16 windows (T = 256 tokens; BASELINE config 5).  One workgroup = (window, head,
+// stream), 8 waves = the 8 blocks of 32 queries.  A 256x256 fp32 score tile per head would be 256 KB — more than
+// the CU's LDS — so each wave walks the 8 key tiles of 32 keys with an online softmax: running max m, the output
+// accumulator rescaled by exp2(m_old - m_new) per tile, and the denominator carried by the all-ones row of V^T so it
+// is rescaled together with the numerator.  The relative-position bias (+ shift mask) for the whole window is
+// precomputed per launch into a [4 variants][256 keys][256 queries] matrix in global memory (L2-resident, 1 MB per
+// stream) and loaded as the C operand of each tile's first MFMA.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void bias16_build_kernel(const float* __restrict__ t0, const float* __restrict__ t1,
+                                                           float* __restrict__ dst, int nprob) {
+    constexpr int WH = 16, WW = 16, T = 256, TW = 2 * WW - 1;
+    const int64_t total = (int64_t)nprob * 4 * T * T;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int q = (int)(e % T), key = (int)((e / T) % T), variant = (int)((e / (T * T)) % 4), p = (int)(e / (4 * T * T));
+        const int ky = key / WW, kx = key % WW, qy = q / WW, qx = q % WW;
+        float v = (p ? t1 : t0)[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
+        const bool my = (variant & 2) && ((ky >= WH - WH / 2) != (qy >= WH - WH / 2));
+        const bool mx = (variant & 1) && ((kx >= WW - WW / 2) != (qx >= WW - WW / 2));
+        if (my || mx) v = -1e10f;   // scores[mask] = -1e10 (a001:310)
+        dst[e] = v * kLog2e;
+    }
+}
+
+struct Attn16Args {
+    const float* Q[2]; const float* K[2]; const float* V[2]; float* O[2];
+    const float* bias_full;   // [nprob][4][256][256]
+    int ldq, ldk, ldv, ldo, B, H, W, heads, shift;
+};
+
+template <int D>
+__global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
+    constexpr int T = 256, WH = 16, WW = 16, QS = cround(D, 8), QKS = cceil(D, 16), MT = cceil(D, 32), VRS = T + 8;
+    constexpr int VEC = (D % 4 == 0) ? 4 : ((D % 2 == 0) ? 2 : 1);
+    constexpr int CPT = D / VEC, NCHUNK = T * CPT, NIT = cceil(NCHUNK, 512);
+    extern __shared__ __attribute__((aligned(16))) char sm16[];
+    bf16* qimg = reinterpret_cast<bf16*>(sm16);                    // [256][QS]
+    bf16* kimg = qimg + T * QS;
+    f16* vt = reinterpret_cast<f16*>(kimg + T * QS);               // [D + 1][VRS]; row D = 1.0
+
+    const int p = blockIdx.z, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, qb = tid >> 6;
+    const int H = a.H, W = a.W, nwx = W / WW, nwy = H / WH;
+    const int win = blockIdx.x;
+    const int b = win / (nwx * nwy), wrem = win % (nwx * nwy), wy = wrem / nwx, wx = wrem % nwx;
+    const int sh = a.shift ? WH / 2 : 0, sw = a.shift ? WW / 2 : 0;
+    const float qscale = kLog2e / sqrtf((float)D);
+
+    for (int i = tid; i < VRS; i += 512) vt[D * VRS + i] = (f16)1.0f;
+    if constexpr (QS != D) {
+        for (int i = tid; i < T * (QS - D); i += 512) {
+            const int tok = i / (QS - D), c = D + i % (QS - D);
+            qimg[tok * QS + c] = (bf16)0.f;
+            kimg[tok * QS + c] = (bf16)0.f;
+        }
+    }
+    float qv[NIT][VEC], kv[NIT][VEC], vv[NIT][VEC];
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * 512;
+        if (e < NCHUNK) {
+            const int tok = e / CPT, c0 = (e % CPT) * VEC;
+            const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
+            const int64_t t = ((int64_t)b * H + oy) * W + ox;
+            const float* qp = a.Q[p] + t * a.ldq + head * D + c0;
+            const float* kp = a.K[p] + t * a.ldk + head * D + c0;
+            const float* vp = a.V[p] + t * a.ldv + head * D + c0;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) { qv[it][j] = qp[j]; kv[it][j] = kp[j]; vv[it][j] = vp[j]; }   // adjacent: hipcc merges into one vector load
+        }
+    }
+#pragma unroll
+    for (int it = 0; it < NIT; ++it) {
+        const int e = tid + it * 512;
+        if (e < NCHUNK) {
+            const int tok = e / CPT, c0 = (e % CPT) * VEC;
+            const int k16 = tok & 15;
+            const int vpos = (tok & ~15) | (((k16 >> 2) & 1) << 3) | (((k16 >> 3) << 2) | (k16 & 3));   // vt_pos for any number of key tiles
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) {
+                qimg[tok * QS + c0 + j] = (bf16)(qv[it][j] * qscale);
+                kimg[tok * QS + c0 + j] = (bf16)kv[it][j];
+                vt[(c0 + j) * VRS + vpos] = (f16)vv[it][j];
+            }
+        }
+    }
+    __syncthreads();
+
+    const int r = lane & 31, hf = lane >> 5;
+    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const int q = 32 * qb + r;
+    const int variant = a.shift ? ((wy == nwy - 1) * 2 + (wx == nwx - 1)) : 0;
+    const float* bias = a.bias_full + ((int64_t)(p * 4 + variant) * T) * T + q;
+    bf16x8 qf[QKS];
+#pragma unroll
+    for (int ks = 0; ks < QKS; ++ks)
+        qf[ks] = (ks * 16 + 8 * hf + 8 <= QS) ? *reinterpret_cast<const bf16x8*>(qimg + q * QS + ks * 16 + 8 * hf) : zero8;
+    f32x16 o[MT];
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) o[mt][i] = 0.f;
+    float m = -INFINITY;
+    for (int kt = 0; kt < T / 32; ++kt) {
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = bias[(int64_t)(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hf) * T];
+        const bf16* krow = kimg + (32 * kt + r) * QS;
+#pragma unroll
+        for (int ks = 0; ks < QKS; ++ks) {
+            const bf16x8 ka = (ks * 16 + 8 * hf + 8 <= QS) ? *reinterpret_cast<const bf16x8*>(krow + ks * 16 + 8 * hf) : zero8;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], acc, 0, 0, 0);
+        }
+        float mt_ = max3f(acc[0], acc[1], acc[2]);
+#pragma unroll
+        for (int i = 3; i < 15; i += 2) mt_ = max3f(mt_, acc[i], acc[i + 1]);
+        mt_ = fmaxf(mt_, acc[15]);
+        mt_ = fmaxf(mt_, __shfl_xor(mt_, 32));
+        const float m_new = fmaxf(m, mt_);
+        const float rescale = __builtin_amdgcn_exp2f(m - m_new);   // first tile: exp2(-inf) = 0 on a zero accumulator
+        m = m_new;
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) o[mt][i] *= rescale;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = __builtin_amdgcn_exp2f(acc[i] - m_new);
+#pragma unroll
+        for (int s2 = 0; s2 < 2; ++s2) {
+            f16x8 pf;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) pf[e] = (f16)acc[8 * s2 + e];
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt) {
+                const int c = mt * 32 + r;
+                const f16x8 va = *reinterpret_cast<const f16x8*>(vt + (c < D ? c : D) * VRS + kt * 32 + s2 * 16 + 8 * hf);
+                o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pf, o[mt], 0, 0, 0);
+            }
+        }
+    }
+    constexpr int LM = D / 32, LI = (D & 3) + 4 * ((D & 31) >> 3), LH = (D >> 2) & 1;
+    float l = o[LM][LI];
+    const float l_other = __shfl_xor(l, 32);
+    l = (hf == LH) ? l : l_other;
+    const float inv = 1.0f / l;
+    const int oy = (wy * WH + q / WW + sh) % H, ox = (wx * WW + q % WW + sw) % W;
+    float* orow = a.O[p] + (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int i = 0; i < 16; i += 4) {
+            const int c = mt * 32 + 8 * (i >> 2) + 4 * hf;
+            if constexpr (D % 4 == 0) {
+                if (c < D) *reinterpret_cast<float4*>(orow + c) = make_float4(o[mt][i] * inv, o[mt][i + 1] * inv, o[mt][i + 2] * inv, o[mt][i + 3] * inv);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c + j < D) orow[c + j] = o[mt][i + j] * inv;
+            }
+        }
+}
+
+template <int D>
+static int launch_attn16_t(const Attn16Args& a, int nprob, hipStream_t stream) {
+    constexpr int QS = cround(D, 8);
+    constexpr size_t lds = size_t(2) * 256 * QS * 2 + size_t(D + 1) * (256 + 8) * 2;
+    static std::once_flag once;
+    static hipError_t attr_err = hipSuccess;
+    if (lds > 64 * 1024)
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_core_mfma16_kernel<D>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        });
+    if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(attn16): %s", hipGetErrorString(attr_err));
+    const int nwin = a.B * (a.H / 16) * (a.W / 16);
+    hipLaunchKernelGGL((attn_core_mfma16_kernel<D>), dim3(nwin, a.heads, nprob), dim3(512), lds, stream, a);
+    return check_launch("attn_core_mfma16");
+}
+
+size_t attn_core_mfma16_scratch_floats(int nprob) { return (size_t)nprob * 4 * 256 * 256; }
+
+int launch_attn_core_mfma16(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
+                            const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
+                            int heads, int head_dim, int shift, float* bias_scratch, hipStream_t stream) {
+    if (!bias_scratch) return fail(SWF_ERR_WORKSPACE, "attn_core_mfma16: no bias scratch");
+    hipLaunchKernelGGL(bias16_build_kernel, dim3(512), dim3(256), 0, stream, table[0], nprob > 1 ? table[1] : table[0], bias_scratch, nprob);
+    SWF_TRY(check_launch("bias16_build"));
+    Attn16Args a{};
+    for (int i = 0; i < nprob; ++i) { a.Q[i] = Q[i]; a.K[i] = K[i]; a.V[i] = V[i]; a.O[i] = O[i]; }
+    a.bias_full = bias_scratch;
+    a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.W = W; a.heads = heads; a.shift = shift;
+    switch (head_dim) {
+        case 3: return launch_attn16_t<3>(a, nprob, stream);
+        case 6: return launch_attn16_t<6>(a, nprob, stream);
+        case 12: return launch_attn16_t<12>(a, nprob, stream);
+        case 24: return launch_attn16_t<24>(a, nprob, stream);
+        case 48: return launch_attn16_t<48>(a, nprob, stream);
+    }
+    return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma16: head_dim %d", head_dim);
+}
+
+bool attn_core_mfma16_supported(int wh, int ww, int head_dim) {
+    return wh == 16 && ww == 16 && (head_dim == 3 || head_dim == 6 || head_dim == 12 || head_dim == 24 || head_dim == 48);
+}
+
 bool attn_core_mfma_supported(int wh, int ww, int head_dim) {
     return wh == 8 && ww == 8 && (head_dim == 3 || head_dim == 6 || head_dim == 12 || head_dim == 24 || head_dim == 48);
 }

@@ -59,6 +59,8 @@ static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn
     }
     const int64_t sk_floats = fast ? std::max(splitk_need(C, 3 * nstream * N * HD), splitk_need(HD, nstream * N * C)) : 0;
     float* sk = fast ? ws.floats(sk_floats) : nullptr;
+    const bool win16 = fast && attn_core_mfma16_supported(d.win_h, d.win_w, d.head_dim);
+    float* bias16 = win16 ? ws.floats((int64_t)attn_core_mfma16_scratch_floats(nstream)) : nullptr;
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "attention workspace too small (need %zu B)", ws.used);
     GemmBatch gb{};
     gb.scratch = sk; gb.scratch_floats = sk_floats;
@@ -79,7 +81,13 @@ static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn
     } else {
         SWF_TRY(launch_gemm(fast, gb, nstream * 3, (int)N, HD, C, C, HD, 0, stream));
     }
-    if (fast && attn_core_mfma_supported(d.win_h, d.win_w, d.head_dim)) {
+    if (win16) {
+        const float* qq[2] = {qkv[0][0], qkv[1][0]};
+        const float* kk[2] = {qkv[0][1], qkv[1][1]};
+        const float* vv[2] = {qkv[0][2], qkv[1][2]};
+        const float* tt[2] = {prm[0]->bias_table, nstream == 2 ? prm[1]->bias_table : nullptr};
+        SWF_TRY(launch_attn_core_mfma16(qq, kk, vv, o, tt, nstream, HD, HD, HD, HD, B, H, W, d.heads, d.head_dim, d.shift, bias16, stream));
+    } else if (fast && attn_core_mfma_supported(d.win_h, d.win_w, d.head_dim)) {
         const float* qq[2] = {qkv[0][0], qkv[1][0]};
         const float* kk[2] = {qkv[0][1], qkv[1][1]};
         const float* vv[2] = {qkv[0][2], qkv[1][2]};
@@ -102,7 +110,8 @@ static size_t attention_generic_ws(const swf_attn_desc& d, int nstream, int B, i
     const int64_t N = (int64_t)B * H * W, HD = (int64_t)d.heads * d.head_dim;
     size_t total = 0;
     for (int s = 0; s < nstream; ++s) total += carve_bytes({N * HD, N * HD, N * HD, N * HD});
-    return total + carve_bytes({std::max(splitk_need(d.channels, 3 * nstream * N * HD), splitk_need((int)HD, nstream * N * d.channels))});
+    return total + carve_bytes({std::max(splitk_need(d.channels, 3 * nstream * N * HD), splitk_need((int)HD, nstream * N * d.channels))}) +
+           carve_bytes({(int64_t)attn_core_mfma16_scratch_floats(nstream)});
 }
 
 static int check_stream_params(const swf_block_stream_params* p, const char* which, bool need_attn, bool need_mlp) {

@@ -307,3 +307,25 @@ def test_ragged_640x512_vs_oracle(precision):
         _close(out, ref, 5e-5)
     else:
         _close(out, ref, TOL_FAST_L2, TOL_FAST_MAX)
+
+
+@pytest.mark.parametrize("case", [(24, 3, 96, (1, 32, 48), True, True), (48, 6, 192, (2, 16, 32), True, False),
+                                  (96, 12, 384, (1, 16, 16), True, True), (384, 48, 1536, (1, 16, 16), False, True)],
+                         ids=["C24", "C48", "C96_onewin", "C384_onewin"])
+def test_window16_block_fast_vs_oracle(case):
+    """16x16 windows (BASELINE config 5): the fast tier runs the MFMA attention core with online softmax over key
+    tiles (256-token windows do not fit a score tile in LDS); checked against the oracle incl. a single-window map,
+    where the shift mask covers 75 % of the entries."""
+    c, d, hid, (b, h, w), shift, cross = case
+    m = BasicBlock(c, 8, d, (16, 16), shift, True, cross, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
+    load_recipe_into(m, seed=31, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, y = G.randn((b, c, h, w), 701), G.randn((b, c, h, w), 702)
+    rx, ry = O.basic_block(sd, "", x, y, cross=cross, shift=shift, num_heads=8, dims_per_head=d, window_size=(16, 16))
+    m.to(DEV)
+    m.precision = "fast"
+    ox, oy = m(x.to(DEV), y.to(DEV))
+    _close(ox, rx, TOL_FAST_L2, TOL_FAST_MAX)
+    _close(oy, ry, TOL_FAST_L2, TOL_FAST_MAX)
+    ox2, oy2 = m(x.to(DEV), y.to(DEV))
+    assert torch.equal(ox, ox2) and torch.equal(oy, oy2)
