@@ -180,7 +180,7 @@ __device__ __forceinline__ void layernorm_regs(const float4 (&res)[G::NTK], bf16
     }
     var += __shfl_xor(var, 16);
     var += __shfl_xor(var, 32);
-    const float rstd = 1.0f / sqrtf(var * (1.0f / C) + 1e-5f);
+    const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / C) + 1e-5f);   // v_rsq_f32 (1 ulp) instead of an IEEE divide + sqrt
 #pragma unroll
     for (int nt = 0; nt < G::NTK; ++nt) {
         const int c0 = nt * 16 + 4 * g;
