@@ -329,3 +329,53 @@ def test_window16_block_fast_vs_oracle(case):
     _close(oy, ry, TOL_FAST_L2, TOL_FAST_MAX)
     ox2, oy2 = m(x.to(DEV), y.to(DEV))
     assert torch.equal(ox, ox2) and torch.equal(oy, oy2)
+
+
+_ODD = [  # C, heads, d, win, hidden, (B,H,W), shift, cross — shapes no fused kernel covers
+    (5, 3, 2, (2, 3), 7, (2, 4, 9), True, True),        # odd C, heads*d != C, rectangular window, scalar (non-float4) paths
+    (10, 2, 5, (4, 8), 20, (1, 8, 16), True, False),
+    (7, 1, 7, (7, 7), 3, (1, 14, 7), True, True),        # one head, hidden < C
+    (36, 4, 9, (3, 3), 50, (3, 6, 9), False, True),
+    (24, 8, 3, (7, 7), 96, (1, 14, 21), True, True),     # model dims with the reference's default window 7
+    (64, 2, 64, (4, 4), 128, (1, 8, 8), True, False),    # head_dim at the attention core's limit (64)
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+@pytest.mark.parametrize("case", _ODD, ids=[f"C{c[0]}_h{c[1]}x{c[2]}_w{c[3][0]}x{c[3][1]}" for c in _ODD])
+def test_basic_block_odd_shapes_vs_oracle(case, precision):
+    c, nh, d, win, hid, (b, h, w), shift, cross = case
+    m = BasicBlock(c, nh, d, win, shift, True, cross, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
+    load_recipe_into(m, seed=41, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, y = G.randn((b, c, h, w), 801), G.randn((b, c, h, w), 802)
+    rx, ry = O.basic_block(sd, "", x, y, cross=cross, shift=shift, num_heads=nh, dims_per_head=d, window_size=win)
+    m.to(DEV)
+    m.precision = precision
+    ox, oy = m(x.to(DEV), y.to(DEV))
+    tol, tmax = (TOL_FP32, None) if precision == "fp32" else (TOL_FAST_L2, TOL_FAST_MAX)
+    _close(ox, rx, tol, tmax)
+    _close(oy, ry, tol, tmax)
+
+
+def test_single_path_block_and_pair():
+    """use_dual_path=False (reference a012:84-101 smoke loop): one stream, cross flag ignored (a002:83)."""
+    m = SelfAndCrossBlockPair(8, 2, 4, (4, 4), False, True, 0.0, 0.0, 16, _elu(), 0.0).eval()
+    load_recipe_into(m, seed=51, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = G.randn((2, 8, 8, 12), 901)
+    # oracle composition for a single stream: every block is self-attention on x
+    r = x
+    for grp in ("self_att_block.", "cross_att_block."):
+        for blk, shift in (("normal_window_block.", False), ("shifted_window_block.", True)):
+            p = grp + blk
+            n = O.layer_norm_channels(r, sd[p + "stage_1.norm_layer_1.weight"], sd[p + "stage_1.norm_layer_1.bias"])
+            r = r + O.window_attention(sd, p + "auto_path_win_att.window_attention_x.", n, n, n, num_heads=2, dims_per_head=4,
+                                       window_size=(4, 4), use_cyclic_shift=shift)
+            n = O.layer_norm_channels(r, sd[p + "stage_2.norm_layer_1.weight"], sd[p + "stage_2.norm_layer_1.bias"])
+            hdn = torch.nn.functional.elu(torch.nn.functional.conv2d(n, sd[p + "auto_path_mlp.mlp_x_1.weight"], sd[p + "auto_path_mlp.mlp_x_1.bias"]))
+            r = r + torch.nn.functional.conv2d(hdn, sd[p + "auto_path_mlp.mlp_x_2.weight"], sd[p + "auto_path_mlp.mlp_x_2.bias"])
+    m.to(DEV)
+    out = m(x.to(DEV))
+    assert isinstance(out, torch.Tensor)
+    _close(out, r, 2e-5)
