@@ -713,30 +713,38 @@ int launch_attn_core(const AttnCoreBatch& batch, int nprob, int ldq, int ldk, in
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * n - 2 - i; }  // bottom/right only
 
+// VEC = 4 when Cin % 4 == 0 (a float4 never straddles two source pixels), else 1.  32-bit index arithmetic
+// (the launcher falls back to VEC = 1 / 64-bit only through the generic path below when counts overflow).
+template <int VEC>
 __global__ __launch_bounds__(256) void merge_gather_kernel(PtrPair pp, int B, int H, int W, int Cin, int mh, int mw,
                                                            int Hm, int Wm, int Ho, int Wo) {
     const float* in = pp.in[blockIdx.y];
     float* out = pp.out[blockIdx.y];
-    const int K = mh * mw * Cin;
-    const int64_t total = (int64_t)B * Ho * Wo * K;
+    const int Kv = mh * mw * Cin / VEC, Cv = Cin / VEC;
+    const int64_t total = (int64_t)B * Ho * Wo * Kv;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int kc = (int)(e % K);
-        int64_t n = e / K;
-        const int ox = (int)(n % Wo); n /= Wo;
-        const int oy = (int)(n % Ho);
-        const int b = (int)(n / Ho);
+        const int kc = (int)(e % Kv);
+        const int n = (int)(e / Kv);                 // output token (fits 32 bits: checked by the launcher)
+        const int ox = n % Wo, t = n / Wo, oy = t % Ho, b = t / Ho;
         const int my = reflect_idx(oy, Hm), mx = reflect_idx(ox, Wm);   // window pad of the merged map
-        const int c = kc % Cin, pq = kc / Cin, pw = pq % mw, ph = pq / mw;
+        const int c = kc % Cv, pq = kc / Cv, pw = pq % mw, ph = pq / mw;
         const int iy = reflect_idx(my * mh + ph, H), ix = reflect_idx(mx * mw + pw, W);  // merge pad of the input
-        out[e] = in[(((int64_t)b * H + iy) * W + ix) * Cin + c];
+        const int64_t src = (((int64_t)b * H + iy) * W + ix) * Cin + c * VEC;
+        if constexpr (VEC == 4) *reinterpret_cast<float4*>(out + e * 4) = *reinterpret_cast<const float4*>(in + src);
+        else out[e] = in[src];
     }
 }
 
 int launch_merge_gather(const PtrPair& pp, int nprob, int B, int H, int W, int Cin, int mh, int mw, int Hm, int Wm,
                         int Ho, int Wo, hipStream_t stream) {
-    const int64_t total = (int64_t)B * Ho * Wo * mh * mw * Cin;
+    if ((int64_t)B * Ho * Wo > INT32_MAX) return fail(SWF_ERR_UNSUPPORTED, "merge_gather: more than 2^31 tokens");
+    bool vec = Cin % 4 == 0;
+    for (int i = 0; i < nprob; ++i)
+        if ((reinterpret_cast<uintptr_t>(pp.in[i]) | reinterpret_cast<uintptr_t>(pp.out[i])) % 16) vec = false;
+    const int64_t total = (int64_t)B * Ho * Wo * mh * mw * Cin / (vec ? 4 : 1);
     dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192), nprob);
-    hipLaunchKernelGGL(merge_gather_kernel, grid, dim3(256), 0, stream, pp, B, H, W, Cin, mh, mw, Hm, Wm, Ho, Wo);
+    if (vec) hipLaunchKernelGGL(merge_gather_kernel<4>, grid, dim3(256), 0, stream, pp, B, H, W, Cin, mh, mw, Hm, Wm, Ho, Wo);
+    else hipLaunchKernelGGL(merge_gather_kernel<1>, grid, dim3(256), 0, stream, pp, B, H, W, Cin, mh, mw, Hm, Wm, Ho, Wo);
     return check_launch("merge_gather");
 }
 
@@ -782,32 +790,50 @@ int launch_crop(const PtrPair& pp, int nprob, int B, int Hp, int Wp, int Hm, int
     return check_launch("crop");
 }
 
+template <int VEC>
 __global__ __launch_bounds__(256) void unmerge_scatter_kernel(PtrPair pp, int B, int Hm, int Wm, int Cout, int mh, int mw,
                                                               int Hout, int Wout) {
     const float* z = pp.in[blockIdx.y];
     float* out = pp.out[blockIdx.y];
     const float* skip = pp.aux[blockIdx.y];
-    const int64_t total = (int64_t)B * Hout * Wout * Cout;
+    const int Cv = Cout / VEC;
+    const int64_t total = (int64_t)B * Hout * Wout * Cv;
     const int Kz = mh * mw * Cout;
     for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(e % Cout);
-        int64_t n = e / Cout;
-        const int x = (int)(n % Wout); n /= Wout;
-        const int y = (int)(n % Hout);
-        const int b = (int)(n / Hout);
+        const int c = (int)(e % Cv) * VEC;
+        const int n = (int)(e / Cv);                 // output pixel (fits 32 bits: checked by the launcher)
+        const int x = n % Wout, t = n / Wout, y = t % Hout, b = t / Hout;
         const int my = y / mh, ph = y % mh, mx = x / mw, pw = x % mw;
-        float v = z[(((int64_t)b * Hm + my) * Wm + mx) * Kz + (ph * mw + pw) * Cout + c];
-        v = elu1(v);
-        if (skip) v += skip[e];
-        out[e] = v;
+        const int64_t src = (((int64_t)b * Hm + my) * Wm + mx) * Kz + (ph * mw + pw) * Cout + c;
+        if constexpr (VEC == 4) {
+            float4 v = *reinterpret_cast<const float4*>(z + src);
+            v.x = elu1(v.x); v.y = elu1(v.y); v.z = elu1(v.z); v.w = elu1(v.w);
+            if (skip) {
+                const float4 k = *reinterpret_cast<const float4*>(skip + e * 4);
+                v.x += k.x; v.y += k.y; v.z += k.z; v.w += k.w;
+            }
+            *reinterpret_cast<float4*>(out + e * 4) = v;
+        } else {
+            float v = elu1(z[src]);
+            if (skip) v += skip[e];
+            out[e] = v;
+        }
     }
 }
 
 int launch_unmerge_scatter(const PtrPair& pp, int nprob, int B, int Hm, int Wm, int Cout, int mh, int mw, int Hout,
                            int Wout, hipStream_t stream) {
-    const int64_t total = (int64_t)B * Hout * Wout * Cout;
+    if ((int64_t)B * Hout * Wout > INT32_MAX) return fail(SWF_ERR_UNSUPPORTED, "unmerge_scatter: more than 2^31 pixels");
+    bool vec = Cout % 4 == 0;
+    for (int i = 0; i < nprob; ++i) {
+        uintptr_t bits = reinterpret_cast<uintptr_t>(pp.in[i]) | reinterpret_cast<uintptr_t>(pp.out[i]);
+        if (pp.aux[i]) bits |= reinterpret_cast<uintptr_t>(pp.aux[i]);
+        if (bits % 16) vec = false;
+    }
+    const int64_t total = (int64_t)B * Hout * Wout * Cout / (vec ? 4 : 1);
     dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 8192), nprob);
-    hipLaunchKernelGGL(unmerge_scatter_kernel, grid, dim3(256), 0, stream, pp, B, Hm, Wm, Cout, mh, mw, Hout, Wout);
+    if (vec) hipLaunchKernelGGL(unmerge_scatter_kernel<4>, grid, dim3(256), 0, stream, pp, B, Hm, Wm, Cout, mh, mw, Hout, Wout);
+    else hipLaunchKernelGGL(unmerge_scatter_kernel<1>, grid, dim3(256), 0, stream, pp, B, Hm, Wm, Cout, mh, mw, Hout, Wout);
     return check_launch("unmerge_scatter");
 }
 
