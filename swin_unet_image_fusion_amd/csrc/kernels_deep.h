@@ -1,0 +1,47 @@
+// Fast tier for the deep levels (C >= 128: few tokens, large weights): the linears of a BasicBlock as
+// separate GEMMs on PRE-SPLIT bf16 operands.  Every GEMM input is written by its producer (LayerNorm,
+// attention core, fc1 epilogue, weight pack) as two bf16 planes hi = bf16(v), lo = bf16(v - hi), so the
+// GEMM stages 16-byte chunks straight into LDS without conversion work and runs the bf16x3 scheme
+// (lo.hi + hi.lo + hi.hi, fp32 accumulate) on v_mfma_f32_32x32x16_bf16 with 128x128 / 128x64 / 64x64 tiles.
+#pragma once
+#include "kernels_generic.h"
+
+namespace swf {
+
+using bf16_raw = unsigned short;   // storage type of a bf16 plane element in host-visible signatures
+
+struct SpGemmProb {
+    const bf16_raw* a_hi; const bf16_raw* a_lo;   // activations [M][K]
+    const bf16_raw* w_hi; const bf16_raw* w_lo;   // weights [N][K] (nn.Linear layout)
+    const float* bias;                            // [N] or nullptr
+    const float* res;                             // SP_EPI_F32: [M][ldo] added to the result, or nullptr
+    float* out;                                   // SP_EPI_F32: [M][ldo]
+    bf16_raw* o_hi; bf16_raw* o_lo;               // SP_EPI_ELU_SPLIT: planes [M][N] of ELU(acc + bias)
+};
+struct SpGemmBatch {
+    SpGemmProb p[kMaxProb];
+    float* scratch = nullptr;          // split-K partials (only used when K >= kSpSplitKMinK)
+    int64_t scratch_floats = 0;
+};
+enum { SP_EPI_F32 = 0, SP_EPI_ELU_SPLIT = 1 };
+
+bool gemm_sp_supported(int N, int K);
+// K slices as a function of K alone (batch shards must stay bit-identical): floats of scratch = slices*nprob*M*N
+int gemm_sp_splitk_for(int K, int epi);
+int launch_gemm_sp(const SpGemmBatch& batch, int nprob, int M, int N, int K, int ldo, int epi, hipStream_t stream);
+
+// fp32 [n] -> planes hi[n], lo[n]
+int launch_split_planes(const float* src, bf16_raw* hi, bf16_raw* lo, int64_t n, hipStream_t stream);
+
+// bytes of the pre-split weight image of ONE stream of one block:
+// planes hi|lo of [Wq | Wk | Wv | Wproj | Wfc1 | Wfc2], each in nn.Linear layout
+size_t deep_block_packed_bytes(const swf_block_desc& d);
+bool deep_block_supported(const swf_block_desc& d);
+int pack_deep_block(const swf_block_desc& d, const swf_block_stream_params& p, void* packed, hipStream_t stream);
+
+struct DeepWeights {   // views into one packed image
+    const bf16_raw *q_hi, *q_lo, *k_hi, *k_lo, *v_hi, *v_lo, *p_hi, *p_lo, *w1_hi, *w1_lo, *w2_hi, *w2_lo;
+};
+DeepWeights deep_block_views(const swf_block_desc& d, const void* packed);
+
+}  // namespace swf

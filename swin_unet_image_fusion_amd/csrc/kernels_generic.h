@@ -40,7 +40,12 @@ struct LnGemmBatch { LnGemmProb p[kMaxProb]; };
 bool lngemm_supported(int C);
 int launch_lngemm_bf16x3(const LnGemmBatch& batch, int nprob, int M, int N, int C, int act, hipStream_t stream);
 
-struct LnProb { const float* in; float* out; const float* gamma; const float* beta; };
+struct LnProb {
+    const float* in; float* out; const float* gamma; const float* beta;
+    // optional (vector path only, C % 4 == 0): write the result as split-bf16 planes hi = bf16(v), lo = bf16(v - hi)
+    // instead of fp32 `out` (input format of the deep-level GEMMs, kernels_deep.h)
+    unsigned short* out_hi = nullptr; unsigned short* out_lo = nullptr;
+};
 struct LnBatch { LnProb p[2]; };
 // LayerNorm over the last dim (eps 1e-5, biased variance), optional ELU on the result.
 int launch_layernorm(const LnBatch& batch, int nprob, int64_t tokens, int C, int elu, hipStream_t stream);

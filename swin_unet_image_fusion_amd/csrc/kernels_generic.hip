@@ -559,17 +559,30 @@ __global__ __launch_bounds__(256) void layernorm_vec_kernel(LnBatch batch, int64
             r.z = (v[i].z - mean) * rstd * g.z + b.z;
             r.w = (v[i].w - mean) * rstd * g.w + b.w;
             if (elu) { r.x = elu1(r.x); r.y = elu1(r.y); r.z = elu1(r.z); r.w = elu1(r.w); }
-            y[ch] = r;
+            if (pr.out_hi) {
+                bf16x4_t hi, lo;
+                split4(r, hi, lo);
+                reinterpret_cast<bf16x4_t*>(pr.out_hi + tok * C)[ch] = hi;
+                reinterpret_cast<bf16x4_t*>(pr.out_lo + tok * C)[ch] = lo;
+            } else {
+                y[ch] = r;
+            }
         }
     }
 }
 
 int launch_layernorm(const LnBatch& batch, int nprob, int64_t tokens, int C, int elu, hipStream_t stream) {
     bool vec = (C % 4 == 0) && C <= 1024;
+    bool split = false;
+    for (int i = 0; i < nprob; ++i) split |= batch.p[i].out_hi != nullptr;
+    if (split && !vec) return fail(SWF_ERR_UNSUPPORTED, "layernorm: split-plane output needs C %% 4 == 0 and C <= 1024 (C=%d)", C);
     for (int i = 0; i < nprob; ++i) {
         const uintptr_t bits = reinterpret_cast<uintptr_t>(batch.p[i].in) | reinterpret_cast<uintptr_t>(batch.p[i].out) |
                                reinterpret_cast<uintptr_t>(batch.p[i].gamma) | reinterpret_cast<uintptr_t>(batch.p[i].beta);
-        if (bits % 16) vec = false;
+        if (bits % 16) {
+            if (split) return fail(SWF_ERR_UNSUPPORTED, "layernorm: split-plane output needs 16-byte aligned tensors");
+            vec = false;
+        }
     }
     if (vec) {
         const int chunks = C / 4;

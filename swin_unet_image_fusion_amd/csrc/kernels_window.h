@@ -25,7 +25,10 @@ int launch_window_block(const swf_block_desc& d, const void* packed_x, const voi
 bool attn_core_mfma_supported(int wh, int ww, int head_dim);
 int launch_attn_core_mfma(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
                           const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
-                          int heads, int head_dim, int shift, hipStream_t stream);
+                          int heads, int head_dim, int shift, hipStream_t stream, unsigned short* const* O_hi = nullptr,
+                          unsigned short* const* O_lo = nullptr);
+// O_hi / O_lo non-null (head_dim % 4 == 0): the output is written as split-bf16 planes hi = bf16(o), lo = bf16(o - hi)
+// with row stride ldo instead of fp32 O (input format of the deep-level projection GEMM, kernels_deep.h).
 
 // MFMA attention core for 16x16 windows (256 tokens): online softmax over key tiles.  Needs
 // attn_core_mfma16_scratch_floats(nprob) floats of scratch for the per-launch bias (+mask) matrices.

@@ -533,6 +533,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
 // ------------------------------------------------------------------------------------------
 struct AttnMfmaArgs {
     const float* Q[2]; const float* K[2]; const float* V[2]; float* O[2]; const float* table[2];
+    unsigned short* Ohi[2]; unsigned short* Olo[2];   // non-null: O is written as split-bf16 planes (row stride ldo) instead
     int ldq, ldk, ldv, ldo, B, H, W, heads, shift;
 };
 
@@ -673,7 +674,32 @@ __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
         }
     const float inv = 1.0f / l;
     const int oy = (wy * WH + q / WW + sh) % H, ox = (wx * WW + q % WW + sw) % W;
-    float* orow = a.O[p] + (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
+    const int64_t ooff = (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
+    if constexpr (D % 4 == 0) {
+        if (a.Ohi[p]) {   // split-bf16 planes for the deep-level projection GEMM (kernels_deep.h)
+            bf16* hrow = reinterpret_cast<bf16*>(a.Ohi[p]) + ooff;
+            bf16* lrow = reinterpret_cast<bf16*>(a.Olo[p]) + ooff;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const int c = mt * 32 + 8 * (i >> 2) + 4 * hf;
+                    if (c < D) {
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = o[mt][i + j] * inv;
+                            hi[j] = (bf16)v;
+                            lo[j] = (bf16)(v - (float)hi[j]);
+                        }
+                        *reinterpret_cast<bf16x4*>(hrow + c) = hi;
+                        *reinterpret_cast<bf16x4*>(lrow + c) = lo;
+                    }
+                }
+            return;
+        }
+    }
+    float* orow = a.O[p] + ooff;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
@@ -907,9 +933,14 @@ bool attn_core_mfma_supported(int wh, int ww, int head_dim) {
 
 int launch_attn_core_mfma(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
                           const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
-                          int heads, int head_dim, int shift, hipStream_t stream) {
+                          int heads, int head_dim, int shift, hipStream_t stream, unsigned short* const* O_hi,
+                          unsigned short* const* O_lo) {
     AttnMfmaArgs a{};
-    for (int i = 0; i < nprob; ++i) { a.Q[i] = Q[i]; a.K[i] = K[i]; a.V[i] = V[i]; a.O[i] = O[i]; a.table[i] = table[i]; }
+    if (O_hi && head_dim % 4) return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: split-plane output needs head_dim %% 4 == 0");
+    for (int i = 0; i < nprob; ++i) {
+        a.Q[i] = Q[i]; a.K[i] = K[i]; a.V[i] = V[i]; a.O[i] = O ? O[i] : nullptr; a.table[i] = table[i];
+        a.Ohi[i] = O_hi ? O_hi[i] : nullptr; a.Olo[i] = O_hi ? O_lo[i] : nullptr;
+    }
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.W = W; a.heads = heads; a.shift = shift;
     switch (head_dim) {
         case 3: return launch_attn_mfma_t<3>(a, nprob, stream);

@@ -7,7 +7,9 @@
 #include <vector>
 
 #include "kernels_generic.h"
+#include <cstdlib>
 #include "kernels_window.h"
+#include "kernels_deep.h"
 
 namespace swf {
 
@@ -194,6 +196,7 @@ static int mlp_halfblock_generic(const swf_block_desc* desc, const swf_block_str
     return SWF_OK;
 }
 
+static size_t deep_block_ws(const swf_block_desc* d, int nstream, int B, int H, int W);
 static size_t block_generic_ws(const swf_block_desc* d, int nstream, int B, int H, int W) {
     const int64_t N = (int64_t)B * H * W;
     size_t a = 0, m = 0;
@@ -201,7 +204,105 @@ static size_t block_generic_ws(const swf_block_desc* d, int nstream, int B, int 
     a += attention_generic_ws(d->attn, nstream, B, H, W);
     for (int s = 0; s < nstream; ++s) m += carve_bytes({N * d->attn.channels}) + carve_bytes({N * d->hidden});
     m += carve_bytes({std::max(splitk_need(d->attn.channels, nstream * N * d->hidden), splitk_need(d->hidden, nstream * N * d->attn.channels))});
-    return std::max(a, m);
+    return std::max(std::max(a, m), deep_block_ws(d, nstream, B, H, W));
+}
+
+// ---- deep-level composition (fast tier, C >= 128): pre-split bf16 planes between the units ----------
+// LN1 -> planes | Q/K/V GEMMs -> fp32 | MFMA attention core -> planes | proj GEMM (+x) | LN2 -> planes |
+// fc1 GEMM + ELU -> planes | fc2 GEMM (+x, split-K when hidden >= 1024).  `packed_*`: pre-split weight images
+// (pack_deep_block) or nullptr, in which case they are derived into the workspace on every call.
+static size_t deep_block_ws(const swf_block_desc* d, int nstream, int B, int H, int W) {
+    if (!deep_block_supported(*d)) return 0;
+    const int64_t N = (int64_t)B * H * W, C = d->attn.channels, HD = (int64_t)d->attn.heads * d->attn.head_dim, hid = d->hidden;
+    size_t t = 0;
+    for (int s = 0; s < nstream; ++s) {
+        t += carve_bytes({(int64_t)deep_block_packed_bytes(*d) / 4});
+        t += carve_bytes({N * C / 2, N * C / 2, N * HD, N * HD, N * HD, N * HD / 2, N * HD / 2, N * hid / 2, N * hid / 2});
+    }
+    const int64_t sk = std::max((int64_t)gemm_sp_splitk_for((int)HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for((int)hid, SP_EPI_F32));
+    t += carve_bytes({sk > 1 ? sk * nstream * N * C : 0});
+    return t;
+}
+
+static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                           const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
+                           Carver& ws, hipStream_t stream, const void* packed_x, const void* packed_y) {
+    const int nstream = py ? 2 : 1;
+    const int64_t N = (int64_t)B * H * W;
+    const int C = desc->attn.channels, HD = desc->attn.heads * desc->attn.head_dim, hid = desc->hidden;
+    const bool cross = desc->cross && nstream == 2;
+    const swf_block_stream_params* pp[2] = {px, py};
+    const float* xin[2] = {x_in, y_in};
+    float* xout[2] = {x_out, y_out};
+    const void* pk[2] = {packed_x, packed_y};
+    auto planes = [&](int64_t n) { return reinterpret_cast<bf16_raw*>(ws.floats(n / 2)); };
+    bf16_raw *xn_hi[2], *xn_lo[2], *o_hi[2], *o_lo[2], *h_hi[2], *h_lo[2];
+    float* qkv[2][3];
+    void* wbuf[2] = {nullptr, nullptr};
+    for (int s = 0; s < nstream; ++s) {
+        wbuf[s] = ws.floats((int64_t)deep_block_packed_bytes(*desc) / 4);
+        xn_hi[s] = planes(N * C); xn_lo[s] = planes(N * C);
+        for (int i = 0; i < 3; ++i) qkv[s][i] = ws.floats(N * HD);
+        o_hi[s] = planes(N * HD); o_lo[s] = planes(N * HD);
+        h_hi[s] = planes(N * hid); h_lo[s] = planes(N * hid);
+    }
+    const int64_t skn = std::max((int64_t)gemm_sp_splitk_for(HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for(hid, SP_EPI_F32));
+    const int64_t sk_floats = skn > 1 ? skn * nstream * N * C : 0;
+    float* sk = ws.floats(sk_floats);
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "deep block workspace too small (need %zu B)", ws.used);
+    DeepWeights wv[2];
+    for (int s = 0; s < nstream; ++s) {
+        if (!pk[s]) { SWF_TRY(pack_deep_block(*desc, *pp[s], wbuf[s], stream)); pk[s] = wbuf[s]; }
+        wv[s] = deep_block_views(*desc, pk[s]);
+    }
+    // attention half (a004:29-38 around a002:58-82)
+    LnBatch l1{};
+    for (int s = 0; s < nstream; ++s) l1.p[s] = LnProb{xin[s], nullptr, pp[s]->ln1.gamma, pp[s]->ln1.beta, xn_hi[s], xn_lo[s]};
+    SWF_TRY(launch_layernorm(l1, nstream, N, C, 0, stream));
+    SpGemmBatch gq{};
+    for (int s = 0; s < nstream; ++s) {
+        const int kvs = cross ? 1 - s : s;   // K and V of stream s read the other stream's normalised tokens in a cross block
+        const swf_linear* lin[3] = {&pp[s]->attn.q, &pp[s]->attn.k, &pp[s]->attn.v};
+        const bf16_raw* wh[3] = {wv[s].q_hi, wv[s].k_hi, wv[s].v_hi};
+        const bf16_raw* wl[3] = {wv[s].q_lo, wv[s].k_lo, wv[s].v_lo};
+        for (int i = 0; i < 3; ++i) {
+            const int src = i == 0 ? s : kvs;
+            gq.p[s * 3 + i] = SpGemmProb{xn_hi[src], xn_lo[src], wh[i], wl[i], lin[i]->bias, nullptr, qkv[s][i], nullptr, nullptr};
+        }
+    }
+    SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_F32, stream));
+    {
+        const float* qq[2] = {qkv[0][0], qkv[1][0]};
+        const float* kk[2] = {qkv[0][1], qkv[1][1]};
+        const float* vv[2] = {qkv[0][2], qkv[1][2]};
+        const float* tt[2] = {pp[0]->attn.bias_table, nstream == 2 ? pp[1]->attn.bias_table : nullptr};
+        SWF_TRY(launch_attn_core_mfma(qq, kk, vv, nullptr, tt, nstream, HD, HD, HD, HD, B, H, W, desc->attn.heads, desc->attn.head_dim,
+                                      desc->attn.shift, stream, o_hi, o_lo));
+    }
+    SpGemmBatch gp{};
+    gp.scratch = sk; gp.scratch_floats = sk_floats;
+    for (int s = 0; s < nstream; ++s)
+        gp.p[s] = SpGemmProb{o_hi[s], o_lo[s], wv[s].p_hi, wv[s].p_lo, pp[s]->attn.proj.bias, xin[s], xout[s], nullptr, nullptr};
+    SWF_TRY(launch_gemm_sp(gp, nstream, (int)N, C, HD, C, SP_EPI_F32, stream));
+    // MLP half (a004:29-38 around a003:46-50)
+    LnBatch l2{};
+    for (int s = 0; s < nstream; ++s) l2.p[s] = LnProb{xout[s], nullptr, pp[s]->ln2.gamma, pp[s]->ln2.beta, xn_hi[s], xn_lo[s]};
+    SWF_TRY(launch_layernorm(l2, nstream, N, C, 0, stream));
+    SpGemmBatch g1{};
+    for (int s = 0; s < nstream; ++s)
+        g1.p[s] = SpGemmProb{xn_hi[s], xn_lo[s], wv[s].w1_hi, wv[s].w1_lo, pp[s]->fc1.bias, nullptr, nullptr, h_hi[s], h_lo[s]};
+    SWF_TRY(launch_gemm_sp(g1, nstream, (int)N, hid, C, hid, SP_EPI_ELU_SPLIT, stream));
+    SpGemmBatch g2{};
+    g2.scratch = sk; g2.scratch_floats = sk_floats;
+    for (int s = 0; s < nstream; ++s)
+        g2.p[s] = SpGemmProb{h_hi[s], h_lo[s], wv[s].w2_hi, wv[s].w2_lo, pp[s]->fc2.bias, xout[s], xout[s], nullptr, nullptr};
+    return launch_gemm_sp(g2, nstream, (int)N, C, hid, C, SP_EPI_F32, stream);
+}
+
+// bytes of the pre-packed weight image of ONE stream of a block (fused window kernel or deep-level GEMMs); 0 = none
+static size_t block_packed_bytes(const swf_block_desc& d) {
+    const size_t pb = window_block_packed_bytes(d);
+    return pb ? pb : deep_block_packed_bytes(d);
 }
 
 static int check_block(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
@@ -232,6 +333,22 @@ static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_p
         char* w = static_cast<char*>(workspace);
         SWF_TRY(pack_window_block(*desc, *px, *py, w, w + pb, stream));
         return launch_window_block(*desc, w, w + pb, x_in, y_in, x_out, y_out, B, H, W, stream);
+    }
+    auto aligned16 = [](const swf_block_stream_params* p) {
+        if (!p) return true;
+        const void* v[] = {p->ln1.gamma, p->ln1.beta, p->ln2.gamma, p->ln2.beta, p->attn.q.weight, p->attn.k.weight, p->attn.v.weight,
+                           p->attn.proj.weight, p->fc1.weight, p->fc2.weight, p->attn.q.bias, p->attn.k.bias, p->attn.v.bias,
+                           p->attn.proj.bias, p->fc1.bias, p->fc2.bias};
+        uintptr_t bits = 0;
+        for (const void* q : v) bits |= reinterpret_cast<uintptr_t>(q);
+        return bits % 16 == 0;
+    };
+    const uintptr_t tbits = reinterpret_cast<uintptr_t>(x_in) | reinterpret_cast<uintptr_t>(y_in) | reinterpret_cast<uintptr_t>(x_out) |
+                            reinterpret_cast<uintptr_t>(y_out);
+    static const bool no_deep = std::getenv("SWF_NO_DEEP") != nullptr;   // A/B switch for tools/profile_block.py
+    if (deep_block_supported(*desc) && !no_deep && tbits % 16 == 0 && aligned16(px) && aligned16(py)) {
+        Carver ws(workspace, workspace_bytes);
+        return deep_block_impl(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, stream, prepacked_x, prepacked_y);
     }
     {
         Carver ws(workspace, workspace_bytes);
@@ -503,7 +620,7 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
                             void* workspace, size_t workspace_bytes, hipStream_t stream, const char* packed = nullptr) {
     const float* xi = x_in;
     const float* yi = y_in;
-    const size_t pb = packed ? window_block_packed_bytes(*desc) : 0;
+    const size_t pb = packed ? block_packed_bytes(*desc) : 0;
     for (int i = 0; i < 4; ++i) {
         swf_block_desc d = *desc;
         d.cross = i >= 2;          // self pair first, then cross pair (a012:72-73)
@@ -527,13 +644,13 @@ static PackedPlan packed_plan(const swf_model_desc* d) {
     for (int s = 0; s < d->levels; ++s) {
         swf_block_desc be = level_block_desc(d, s, true);
         be.precision = SWF_PREC_FAST;
-        const size_t pb = window_block_packed_bytes(be);
+        const size_t pb = block_packed_bytes(be);
         p.enc_on[s] = pb > 0; p.enc[s] = off; off += 8 * pb;
     }
     for (int j = 0; j < d->levels; ++j) {
         swf_block_desc bd = level_block_desc(d, d->levels - 1 - j, false);
         bd.precision = SWF_PREC_FAST;
-        const size_t pb = window_block_packed_bytes(bd);
+        const size_t pb = block_packed_bytes(bd);
         p.dec_on[j] = pb > 0; p.dec[j] = off; off += 8 * pb;
     }
     p.total = off;
@@ -808,12 +925,18 @@ int swf_model_pack_weights(const swf_model_desc* desc, const float* arena, void*
             if (!(enc ? plan.enc_on[k] : plan.dec_on[k])) continue;
             swf_block_desc bd = level_block_desc(desc, enc ? k : desc->levels - 1 - k, enc);
             bd.precision = SWF_PREC_FAST;
-            const size_t pb = window_block_packed_bytes(bd);
+            const size_t pb = block_packed_bytes(bd);
+            const bool fused = window_block_packed_bytes(bd) > 0;
             char* dst = base + (enc ? plan.enc[k] : plan.dec[k]);
             for (int i = 0; i < 4; ++i) {
                 const swf_block_stream_params px = make_stream_params(arena, enc ? L->enc_blk[k][i][0] : L->dec_blk[k][i][0]);
                 const swf_block_stream_params py = make_stream_params(arena, enc ? L->enc_blk[k][i][1] : L->dec_blk[k][i][1]);
-                SWF_TRY(pack_window_block(bd, px, py, dst + (size_t)(2 * i) * pb, dst + (size_t)(2 * i + 1) * pb, stream));
+                if (fused) {
+                    SWF_TRY(pack_window_block(bd, px, py, dst + (size_t)(2 * i) * pb, dst + (size_t)(2 * i + 1) * pb, stream));
+                } else {
+                    SWF_TRY(pack_deep_block(bd, px, dst + (size_t)(2 * i) * pb, stream));
+                    SWF_TRY(pack_deep_block(bd, py, dst + (size_t)(2 * i + 1) * pb, stream));
+                }
             }
         }
     return SWF_OK;
