@@ -10,6 +10,7 @@
 #include <cstdlib>
 #include "kernels_window.h"
 #include "kernels_deep.h"
+#include "kernels_patch.h"
 
 namespace swf {
 
@@ -384,6 +385,17 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
     SWF_TRY(merge_shapes(H, W, mh, mw, wh, ww, &Hm, &Wm, &Ho, &Wo));
     const int64_t N = (int64_t)B * Ho * Wo;
     const int K = mh * mw * Cin;
+    static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switch
+    if (fast && !no_fused && patch_fused_supported(K, Cout)) {   // one launch: gather -> conv -> LN -> ELU
+        PatchFusedDesc d{};
+        for (int s = 0; s < nstream; ++s) {
+            d.in[s] = in[s]; d.out[s] = out[s]; d.skip[s] = nullptr;
+            d.w[s] = p[s]->conv.weight; d.bias[s] = p[s]->conv.bias; d.gamma[s] = p[s]->ln.gamma; d.beta[s] = p[s]->ln.beta;
+        }
+        d.decoder = 0; d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.mh = mh; d.mw = mw; d.Hm = Hm; d.Wm = Wm; d.Ho = Ho; d.Wo = Wo;
+        d.K = K; d.N = Cout; d.Cout = Cout; d.M = N;
+        return launch_patch_fused(d, nstream, stream);
+    }
     Carver ws(workspace, workspace_bytes);
     float* a[2];
     float* z[2];
@@ -415,6 +427,20 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
     const int64_t N = (int64_t)B * Hm * Wm;
     const int Kz = mh * mw * Cout;
     const bool need_crop = (Hm != Hp) || (Wm != Wp);
+    static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switch
+    // wide outputs on few tokens (level 2 at 256x256: 256 tiles of 192 channels) leave the per-workgroup weight staging
+    // unamortised: the GEMM path below is faster there (measured 49 vs 55 us)
+    const bool few_wide = N < 512 * 64 && Kz > 96;
+    if (fast && !no_fused && !few_wide && patch_fused_supported(Cin, Kz)) {   // one launch: crop -> conv -> LN -> scatter -> ELU (+ skip)
+        PatchFusedDesc d{};
+        for (int s = 0; s < nstream; ++s) {
+            d.in[s] = in[s]; d.out[s] = out[s]; d.skip[s] = skip ? skip[s] : nullptr;
+            d.w[s] = p[s]->conv.weight; d.bias[s] = p[s]->conv.bias; d.gamma[s] = p[s]->ln.gamma; d.beta[s] = p[s]->ln.beta;
+        }
+        d.decoder = 1; d.B = B; d.H = Hp; d.W = Wp; d.Cin = Cin; d.mh = mh; d.mw = mw; d.Hm = Hm; d.Wm = Wm; d.Ho = Hout; d.Wo = Wout;
+        d.K = Cin; d.N = Kz; d.Cout = Cout; d.M = N;
+        return launch_patch_fused(d, nstream, stream);
+    }
     Carver ws(workspace, workspace_bytes);
     float* cr[2] = {nullptr, nullptr};
     float* z[2];
