@@ -34,13 +34,17 @@ int launch_gemm_sp(const SpGemmBatch& batch, int nprob, int M, int N, int K, int
 int launch_split_planes(const float* src, bf16_raw* hi, bf16_raw* lo, int64_t n, hipStream_t stream);
 
 // bytes of the pre-split weight image of ONE stream of one block:
-// planes hi|lo of [Wq | Wk | Wv | Wproj | Wfc1 | Wfc2], each in nn.Linear layout
+// planes hi|lo of [Wq | Wk | Wv | Wproj | Wfc1 | Wfc2], each in nn.Linear layout, then (when the fused MLP kernel
+// covers the shape) fragment-major copies of Wfc1 and Wfc2
 size_t deep_block_packed_bytes(const swf_block_desc& d);
 bool deep_block_supported(const swf_block_desc& d);
 int pack_deep_block(const swf_block_desc& d, const swf_block_stream_params& p, void* packed, hipStream_t stream);
 
 struct DeepWeights {   // views into one packed image
     const bf16_raw *q_hi, *q_lo, *k_hi, *k_lo, *v_hi, *v_lo, *p_hi, *p_lo, *w1_hi, *w1_lo, *w2_hi, *w2_lo;
+    // fc1 / fc2 again in MFMA-fragment-major order for the fused MLP kernel (kernels_mlp.hip), or nullptr:
+    // block (row tile rt of 32 rows, k16 step ks) = 64 lanes x 8 bf16, lane = 32*hf + r holds row 32rt+r, k = 16ks+8hf..+7
+    const bf16_raw *w1f_hi, *w1f_lo, *w2f_hi, *w2f_lo;
 };
 DeepWeights deep_block_views(const swf_block_desc& d, const void* packed);
 

@@ -11,6 +11,7 @@
 // one barrier per step.
 #include "kernels_deep.h"
 #include "kernels_window.h"
+#include "kernels_mlp.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -246,6 +247,22 @@ __global__ __launch_bounds__(256) void split_planes_kernel(const float* __restri
     }
 }
 
+// fp32 [R][K] (R % 32 == 0, K % 16 == 0) -> fragment-major split planes (see DeepWeights)
+__global__ __launch_bounds__(256) void pack_fragmajor_kernel(const float* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo,
+                                                             int R, int K) {
+    const int64_t total = (int64_t)R * K;
+    const int ksteps = K / 16;
+    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t block = e >> 9;
+        const int within = (int)(e & 511), lane = within >> 3, j = within & 7, hf = lane >> 5, r = lane & 31;
+        const int ks = (int)(block % ksteps), rt = (int)(block / ksteps);
+        const float v = src[(int64_t)(32 * rt + r) * K + 16 * ks + 8 * hf + j];
+        const bf16 h = (bf16)v;
+        hi[e] = h;
+        lo[e] = (bf16)(v - (float)h);
+    }
+}
+
 bool gemm_sp_supported(int N, int K) { return N > 0 && K > 0 && N % 4 == 0 && K % 32 == 0; }
 
 int gemm_sp_splitk_for(int K, int epi) { return (epi == SP_EPI_F32 && K >= 1024 && K % 128 == 0) ? 4 : 1; }
@@ -318,12 +335,13 @@ int launch_split_planes(const float* src, bf16_raw* hi, bf16_raw* lo, int64_t n,
 
 // ---- packed weight image of one stream of one block ----------------------------------------------------
 namespace {
-struct DeepSizes { int64_t qkv, proj, w1, w2, total; };
+struct DeepSizes { int64_t qkv, proj, w1, w2, fm, total; };
 DeepSizes deep_sizes(const swf_block_desc& d) {
     const int64_t C = d.attn.channels, HD = (int64_t)d.attn.heads * d.attn.head_dim, hid = d.hidden;
     DeepSizes s;
     s.qkv = HD * C; s.proj = C * HD; s.w1 = hid * C; s.w2 = C * hid;
-    s.total = 3 * s.qkv + s.proj + s.w1 + s.w2;
+    s.fm = mlp_fused_supported((int)C, (int)hid) ? s.w1 + s.w2 : 0;   // fragment-major copies of fc1 | fc2
+    s.total = 3 * s.qkv + s.proj + s.w1 + s.w2 + s.fm;
     return s;
 }
 }  // namespace
@@ -350,7 +368,12 @@ DeepWeights deep_block_views(const swf_block_desc& d, const void* packed) {
     w.v_hi = hi + o; w.v_lo = lo + o; o += s.qkv;
     w.p_hi = hi + o; w.p_lo = lo + o; o += s.proj;
     w.w1_hi = hi + o; w.w1_lo = lo + o; o += s.w1;
-    w.w2_hi = hi + o; w.w2_lo = lo + o;
+    w.w2_hi = hi + o; w.w2_lo = lo + o; o += s.w2;
+    w.w1f_hi = w.w1f_lo = w.w2f_hi = w.w2f_lo = nullptr;
+    if (s.fm) {
+        w.w1f_hi = hi + o; w.w1f_lo = lo + o; o += s.w1;
+        w.w2f_hi = hi + o; w.w2f_lo = lo + o;
+    }
     return w;
 }
 
@@ -365,6 +388,19 @@ int pack_deep_block(const swf_block_desc& d, const swf_block_stream_params& p, v
     for (int i = 0; i < 6; ++i) {
         SWF_TRY(launch_split_planes(src[i], hi + o, lo + o, n[i], stream));
         o += n[i];
+    }
+    if (s.fm) {
+        const int C = d.attn.channels, hid = d.hidden;
+        const float* fsrc[2] = {p.fc1.weight, p.fc2.weight};
+        const int R[2] = {hid, C}, K[2] = {C, hid};
+        for (int i = 0; i < 2; ++i) {
+            const int64_t n2 = (int64_t)R[i] * K[i];
+            dim3 grid((unsigned)std::min<int64_t>(cdiv64(n2, 256), 4096));
+            hipLaunchKernelGGL(pack_fragmajor_kernel, grid, dim3(256), 0, stream, fsrc[i], reinterpret_cast<bf16*>(hi + o),
+                               reinterpret_cast<bf16*>(lo + o), R[i], K[i]);
+            SWF_TRY(check_launch("pack_fragmajor"));
+            o += n2;
+        }
     }
     return SWF_OK;
 }

@@ -1,0 +1,364 @@
+// Deep-level fast tier: the MLP half of a BasicBlock (a004:29-38 around a003:46-50) in ONE launch:
+//   out = x + fc2(ELU(fc1(LN2(x))))            per stream, C in {128, 192, 256, 384}, hidden % 128 == 0.
+// Replaces LayerNorm + fc1 GEMM + fc2 GEMM (+ split-K reduce) and the round trip of the hidden activations.
+//
+// grid = (64-token tiles, hidden splits, streams), 256 threads = 4 waves.  A workgroup normalises its 64 token rows
+// once (LN2, fp32, two shuffles per row) into a split-bf16 LDS image, then walks its hidden range in chunks of 128:
+//   fc1   wave w owns hidden rows [32w, 32w+32) of the chunk for all 64 tokens: H^T = W1 . xn^T on v_mfma_f32_32x32x16_bf16
+//         (bf16x3: lo.hi + hi.lo + hi.hi, fp32 accumulate), + bias, ELU, split -> LDS image H [64][128] hi / lo
+//   fc2   out^T[C][64] += W2[:, chunk] . H^T; the C/32 output tiles are dealt to the waves (whole tiles = both 32-token
+//         halves; when C/32 % 4 == 2 the last two tiles are dealt as halves) and stay in accumulators across chunks.
+// Weights never touch LDS: the packed image holds fc1 / fc2 a second time in MFMA-fragment-major order (DeepWeights),
+// so a wave's A fragment is ONE contiguous 1-KB load (row-strided fragment loads from the nn.Linear layout cost 2x in
+// this kernel: 32-byte pieces of 128-byte lines); fragments stream through a register ring D = 14 / 16 deep, issued
+// ahead of their MFMAs across phase and chunk boundaries and pinned there with scheduling fences (hipcc otherwise
+// sinks every prefetch next to its use).  The token-side fragments are read from LDS one k16 step ahead.
+// Measured bound: LDS read bandwidth (every wave re-reads all 64 token rows per k16 step).  With S > 1 hidden splits a workgroup writes its partial out tile to
+// scratch and mlp_reduce_kernel adds the S partials in fixed order + bias + residual (bit-reproducible; S depends on the
+// layer shape only, never on the batch).
+#include "kernels_mlp.h"
+
+#include <algorithm>
+#include <cstdlib>
+
+namespace swf {
+
+namespace {
+
+using bf16 = __bf16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+constexpr float kLog2e = 1.4426950408889634f;
+__device__ __forceinline__ float elu_fast(float v) { return v > 0.f ? v : __builtin_amdgcn_exp2f(v * kLog2e) - 1.0f; }
+
+struct MlpArgs {
+    const float* x[2]; float* out[2];
+    const float* gamma[2]; const float* beta[2];
+    const bf16* w1_hi[2]; const bf16* w1_lo[2]; const bf16* w2_hi[2]; const bf16* w2_lo[2];
+    const float* b1[2]; const float* b2[2];
+    float* scratch;          // [stream][split][M][C] partial sums when splits > 1
+    int M, HID, splits, nchunks;
+};
+
+__device__ __forceinline__ void mma3(f32x16& acc, const bf16x8 wh, const bf16x8 wl, const bf16x8 bh, const bf16x8 bl) {
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl, bh, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bl, acc, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc, 0, 0, 0);
+}
+
+template <int C>
+__global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
+    constexpr int KS1 = C / 16;                  // k16 steps of fc1
+    constexpr int T = C / 32;                    // 32-channel output tiles of fc2
+    static_assert(T % 4 == 0 || T % 4 == 2, "C must be a multiple of 64");
+    constexpr int NF = (T - T % 4) / 4;          // whole tiles per wave
+    constexpr int NH = (T % 4) ? 1 : 0;          // + one half tile (one 32-token half)
+    constexpr int NFR = NF + NH;                 // W2 fragments per k16 step
+    constexpr int KS2 = 8;                       // k16 steps per 128-wide hidden chunk
+    constexpr int NFRAG = KS1 + KS2 * NFR;       // weight fragments a wave streams per chunk
+    constexpr int D = (NFRAG % 16 == 0) ? 16 : 14;   // ring depth: ~1 us of MFMA work ahead (L2 / MALL latency under load)
+    static_assert(NFRAG % D == 0, "ring depth must divide the fragment count");
+    constexpr int LDA = C + 8, LDH = 128 + 8;    // row strides (bf16): odd multiples of 16 B
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    bf16* a_hi = reinterpret_cast<bf16*>(smem);
+    bf16* a_lo = a_hi + 64 * LDA;
+    bf16* h_hi = a_lo + 64 * LDA;
+    bf16* h_lo = h_hi + 64 * LDH;
+
+    const int tile = blockIdx.x, split = blockIdx.y, s = blockIdx.z;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hf = lane >> 5;
+    const int HID = a.HID;
+
+    // ---- the wave's weight fragment stream: per chunk KS1 fragments of W1 (its 32 hidden rows), then per k16 step of
+    //      fc2 one fragment per output tile it owns.  The planes are fragment-major (DeepWeights): a fragment is one
+    //      contiguous 1-KB block, lane l reads bytes [16l, 16l+16) ----
+    const bf16* w1h = a.w1_hi[s] + lane * 8;
+    const bf16* w1l = a.w1_lo[s] + lane * 8;
+    const bf16* w2h = a.w2_hi[s] + lane * 8;
+    const bf16* w2l = a.w2_lo[s] + lane * 8;
+    const int half_nt = T - 2 + (wave >> 1), half_tok = wave & 1;
+    const int KSH = HID / 16;   // k16 steps of a whole W2 row
+    int w2blk[NFR];             // first block of the W2 row tile
+#pragma unroll
+    for (int j = 0; j < NFR; ++j) w2blk[j] = (j < NF ? wave + 4 * j : half_nt) * KSH;
+
+    bf16x8 rh[D], rl[D];
+    // fragment f (0 <= f < NFRAG after unrolling: a constant) of the chunk with hidden base hb -> ring slot f % D
+    auto frag_load = [&](int f, int hb) {
+        if (f < KS1) {
+            const int64_t blk = (int64_t)((hb >> 5) + wave) * KS1 + f;
+            rh[f % D] = *reinterpret_cast<const bf16x8*>(w1h + blk * 512);
+            rl[f % D] = *reinterpret_cast<const bf16x8*>(w1l + blk * 512);
+        } else {
+            const int q = f - KS1, ks = q / NFR, j = q % NFR;
+            const int64_t blk = w2blk[j] + (hb >> 4) + ks;
+            rh[f % D] = *reinterpret_cast<const bf16x8*>(w2h + blk * 512);
+            rl[f % D] = *reinterpret_cast<const bf16x8*>(w2l + blk * 512);
+        }
+    };
+
+    const int hb0 = split * a.nchunks * 128;
+#pragma unroll
+    for (int f = 0; f < D; ++f) frag_load(f, hb0);   // in flight during the LayerNorm prologue
+
+    // ---- LN2 of the 64 token rows -> split-bf16 image (4 threads per row) ----
+    {
+        const int row = tid >> 2, sub = tid & 3;
+        const int m = min(tile * 64 + row, a.M - 1);   // rows past M are computed on a clamped copy and never stored
+        const float* xr = a.x[s] + (int64_t)m * C;
+        constexpr int NV = C / 16;
+        float4 v[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            v[i] = *reinterpret_cast<const float4*>(xr + 16 * i + 4 * sub);
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        sum += __shfl_xor(sum, 1);
+        sum += __shfl_xor(sum, 2);
+        const float mean = sum * (1.0f / C);
+        float var = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+        var += __shfl_xor(var, 1);
+        var += __shfl_xor(var, 2);
+        const float rstd = 1.0f / sqrtf(var * (1.0f / C) + 1e-5f);
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 16 * i + 4 * sub;
+            const float4 gm = *reinterpret_cast<const float4*>(a.gamma[s] + c), bt = *reinterpret_cast<const float4*>(a.beta[s] + c);
+            const float n[4] = {(v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y,
+                                (v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w};
+            bf16x4 h, l;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { h[j] = (bf16)n[j]; l[j] = (bf16)(n[j] - (float)h[j]); }
+            *reinterpret_cast<bf16x4*>(a_hi + row * LDA + c) = h;
+            *reinterpret_cast<bf16x4*>(a_lo + row * LDA + c) = l;
+        }
+    }
+    __syncthreads();
+
+    f32x16 acc2[2 * NF + NH];
+#pragma unroll
+    for (int i = 0; i < 2 * NF + NH; ++i)
+#pragma unroll
+        for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
+
+    for (int ch = 0; ch < a.nchunks; ++ch) {
+        const int hb = hb0 + ch * 128;
+        // next chunk's hidden base for the ring's run-ahead; past the last chunk the ring re-reads this chunk's first
+        // fragments (dead loads) instead of branching: a conditional prefetch costs the counted waits their count
+        const int hbn = ch + 1 < a.nchunks ? hb + 128 : hb;
+        // ---- fc1: H^T[32 hidden of this wave][64 tokens] ----
+        f32x16 acc1[2];
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc1[0][e] = 0.f; acc1[1][e] = 0.f; }
+        // the chunk's fc1 bias goes out FIRST: vmcnt retires in order, so a bias load issued after the weight prefetches
+        // would drain the whole ring at the phase boundary
+        float4 b1v[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) b1v[g] = *reinterpret_cast<const float4*>(a.b1[s] + hb + 32 * wave + 8 * g + 4 * hf);
+        __builtin_amdgcn_sched_barrier(0);
+        // B fragments (tokens) are read one k16 step ahead of their MFMAs: the scheduling fences below pin the order
+        // [ring prefetch, next step's LDS reads] -> [this step's MFMAs], so LDS latency hides behind the matrix work
+        bf16x8 bh0, bl0, bh1, bl1;
+        {
+            const int ko = 8 * hf;
+            bh0 = *reinterpret_cast<const bf16x8*>(a_hi + r * LDA + ko); bl0 = *reinterpret_cast<const bf16x8*>(a_lo + r * LDA + ko);
+            bh1 = *reinterpret_cast<const bf16x8*>(a_hi + (32 + r) * LDA + ko); bl1 = *reinterpret_cast<const bf16x8*>(a_lo + (32 + r) * LDA + ko);
+        }
+#pragma unroll
+        for (int f = 0; f < KS1; ++f) {
+            const bf16x8 wh = rh[f % D], wl = rl[f % D];
+            if (f + D < NFRAG) frag_load(f + D, hb);
+            else frag_load(f + D - NFRAG, hbn);
+            const bf16x8 ch0 = bh0, cl0 = bl0, ch1 = bh1, cl1 = bl1;
+            if (f + 1 < KS1) {
+                const int ko = 16 * (f + 1) + 8 * hf;
+                bh0 = *reinterpret_cast<const bf16x8*>(a_hi + r * LDA + ko); bl0 = *reinterpret_cast<const bf16x8*>(a_lo + r * LDA + ko);
+                bh1 = *reinterpret_cast<const bf16x8*>(a_hi + (32 + r) * LDA + ko); bl1 = *reinterpret_cast<const bf16x8*>(a_lo + (32 + r) * LDA + ko);
+            }
+            __builtin_amdgcn_sched_barrier(0);   // keep the prefetch D fragments ahead: hipcc otherwise sinks it next to its use
+            mma3(acc1[0], wh, wl, ch0, cl0);
+            mma3(acc1[1], wh, wl, ch1, cl1);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // bias, ELU, split: register 4g+j of token half t is hidden 32w + 8g + 4hf + j of token 32t + r
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+                const int hl = 32 * wave + 8 * g + 4 * hf;
+                const float4 b = b1v[g];
+                const float v[4] = {elu_fast(acc1[t][4 * g] + b.x), elu_fast(acc1[t][4 * g + 1] + b.y), elu_fast(acc1[t][4 * g + 2] + b.z),
+                                    elu_fast(acc1[t][4 * g + 3] + b.w)};
+                bf16x4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { h[j] = (bf16)v[j]; l[j] = (bf16)(v[j] - (float)h[j]); }
+                *reinterpret_cast<bf16x4*>(h_hi + (32 * t + r) * LDH + hl) = h;
+                *reinterpret_cast<bf16x4*>(h_lo + (32 * t + r) * LDH + hl) = l;
+            }
+        __syncthreads();   // the whole H chunk is in place
+        // ---- fc2: out^T tiles of this wave += W2[:, chunk] . H^T ----
+        bf16x8 xh, xl;   // the half tile's token half
+        {
+            const int ko = 8 * hf;
+            if constexpr (NF > 0) {
+                bh0 = *reinterpret_cast<const bf16x8*>(h_hi + r * LDH + ko); bl0 = *reinterpret_cast<const bf16x8*>(h_lo + r * LDH + ko);
+                bh1 = *reinterpret_cast<const bf16x8*>(h_hi + (32 + r) * LDH + ko); bl1 = *reinterpret_cast<const bf16x8*>(h_lo + (32 + r) * LDH + ko);
+            }
+            if constexpr (NH) {
+                xh = *reinterpret_cast<const bf16x8*>(h_hi + (32 * half_tok + r) * LDH + ko);
+                xl = *reinterpret_cast<const bf16x8*>(h_lo + (32 * half_tok + r) * LDH + ko);
+            }
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS2; ++ks) {
+            bf16x8 wh[NFR], wl[NFR];
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) {
+                const int f = KS1 + ks * NFR + j;
+                wh[j] = rh[f % D]; wl[j] = rl[f % D];
+                if (f + D < NFRAG) frag_load(f + D, hb);
+                else frag_load(f + D - NFRAG, hbn);
+            }
+            const bf16x8 ch0 = bh0, cl0 = bl0, ch1 = bh1, cl1 = bl1, cxh = xh, cxl = xl;
+            if (ks + 1 < KS2) {
+                const int ko = 16 * (ks + 1) + 8 * hf;
+                if constexpr (NF > 0) {
+                    bh0 = *reinterpret_cast<const bf16x8*>(h_hi + r * LDH + ko); bl0 = *reinterpret_cast<const bf16x8*>(h_lo + r * LDH + ko);
+                    bh1 = *reinterpret_cast<const bf16x8*>(h_hi + (32 + r) * LDH + ko); bl1 = *reinterpret_cast<const bf16x8*>(h_lo + (32 + r) * LDH + ko);
+                }
+                if constexpr (NH) {
+                    xh = *reinterpret_cast<const bf16x8*>(h_hi + (32 * half_tok + r) * LDH + ko);
+                    xl = *reinterpret_cast<const bf16x8*>(h_lo + (32 * half_tok + r) * LDH + ko);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int j = 0; j < NFR; ++j) {
+                if (j < NF) {
+                    mma3(acc2[2 * j], wh[j], wl[j], ch0, cl0);
+                    mma3(acc2[2 * j + 1], wh[j], wl[j], ch1, cl1);
+                } else {
+                    mma3(acc2[2 * NF], wh[j], wl[j], cxh, cxl);
+                }
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        __syncthreads();   // H is free for the next chunk
+    }
+
+    // ---- epilogue: register 4g+j of (tile nt, token half t) is channel 32nt + 8g + 4hf + j of token 32t + r ----
+    float* part = a.splits > 1 ? a.scratch + ((int64_t)(s * a.splits + split) * a.M) * C : nullptr;
+#pragma unroll
+    for (int i = 0; i < 2 * NF + NH; ++i) {
+        const int nt = i < 2 * NF ? wave + 4 * (i >> 1) : half_nt;
+        const int t = i < 2 * NF ? (i & 1) : half_tok;
+        const int m = tile * 64 + 32 * t + r;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+            const int c = 32 * nt + 8 * g + 4 * hf;
+            float4 v = make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
+            if (part) {
+                *reinterpret_cast<float4*>(part + (int64_t)m * C + c) = v;
+            } else {
+                const float4 b = *reinterpret_cast<const float4*>(a.b2[s] + c);
+                const float4 x = *reinterpret_cast<const float4*>(a.x[s] + (int64_t)m * C + c);
+                v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
+                *reinterpret_cast<float4*>(a.out[s] + (int64_t)m * C + c) = v;
+            }
+        }
+    }
+}
+
+// out = x + b2 + sum of the hidden-split partials, fixed order
+__global__ __launch_bounds__(256) void mlp_reduce_kernel(MlpArgs a, int C) {
+    const int s = blockIdx.y;
+    const int64_t total = (int64_t)a.M * C, total4 = total >> 2;
+    const float* part = a.scratch + (int64_t)s * a.splits * total;
+    for (int64_t e4 = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e4 < total4; e4 += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t e = e4 << 2;
+        const int c = (int)(e % C);
+        float4 v = *reinterpret_cast<const float4*>(part + e);
+        for (int k = 1; k < a.splits; ++k) {
+            const float4 t = *reinterpret_cast<const float4*>(part + k * total + e);
+            v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+        }
+        const float4 b = *reinterpret_cast<const float4*>(a.b2[s] + c);
+        const float4 x = *reinterpret_cast<const float4*>(a.x[s] + e);
+        v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
+        *reinterpret_cast<float4*>(a.out[s] + e) = v;
+    }
+}
+
+template <int C>
+int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
+    constexpr int lds = (64 * (C + 8) + 64 * (128 + 8)) * 2 * 2;
+    static bool attr_done = false;
+    if (!attr_done && lds > 65536) {
+        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
+            return fail(SWF_ERR_HIP, "mlp_fused: cannot raise the dynamic LDS limit to %d B", lds);
+        attr_done = true;
+    }
+    dim3 grid((a.M + 63) / 64, a.splits, nstream);
+    hipLaunchKernelGGL((mlp_fused_kernel<C>), grid, dim3(256), lds, stream, a);
+    SWF_TRY(check_launch("mlp_fused"));
+    if (a.splits > 1) {
+        dim3 rgrid((unsigned)std::min<int64_t>(cdiv64((int64_t)a.M * C, 1024), 2048), nstream);
+        hipLaunchKernelGGL(mlp_reduce_kernel, rgrid, dim3(256), 0, stream, a, C);
+        return check_launch("mlp_reduce");
+    }
+    return SWF_OK;
+}
+
+}  // namespace
+
+bool mlp_fused_supported(int C, int HID) {
+    return (C == 128 || C == 192 || C == 256 || C == 384) && HID > 0 && HID % 128 == 0 && (int64_t)C * HID < (1 << 30);
+}
+
+// hidden splits as a function of the layer shape alone: about two 128-wide chunks per workgroup
+int mlp_fused_splits(int C, int HID) {
+    if (const char* e = std::getenv("SWF_MLP_SPLITS")) {   // tools: tuning override (must divide HID / 128)
+        const int v = atoi(e);
+        if (v > 0 && (HID / 128) % v == 0) return v;
+    }
+    const int chunks = HID / 128;
+    if (C <= 256) return 1;   // levels with many tokens per weight byte: no split, no reduce pass (measured at C = 192)
+    return chunks % 2 == 0 ? chunks / 2 : chunks;
+}
+
+int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream) {
+    if (!mlp_fused_supported(d.C, d.HID)) return fail(SWF_ERR_UNSUPPORTED, "mlp_fused: C=%d hidden=%d", d.C, d.HID);
+    if (d.M <= 0 || d.M > (1 << 30) / d.C) return fail(SWF_ERR_UNSUPPORTED, "mlp_fused: token count %d", d.M);
+    MlpArgs a{};
+    for (int s = 0; s < nstream; ++s) {
+        a.x[s] = d.x[s]; a.out[s] = d.out[s]; a.gamma[s] = d.gamma[s]; a.beta[s] = d.beta[s];
+        a.w1_hi[s] = reinterpret_cast<const bf16*>(d.w1_hi[s]); a.w1_lo[s] = reinterpret_cast<const bf16*>(d.w1_lo[s]);
+        a.w2_hi[s] = reinterpret_cast<const bf16*>(d.w2_hi[s]); a.w2_lo[s] = reinterpret_cast<const bf16*>(d.w2_lo[s]);
+        a.b1[s] = d.b1[s]; a.b2[s] = d.b2[s];
+    }
+    a.M = d.M; a.HID = d.HID;
+    a.splits = mlp_fused_splits(d.C, d.HID);
+    a.nchunks = d.HID / 128 / a.splits;
+    a.scratch = d.scratch;
+    if (a.splits > 1 && (!d.scratch || (int64_t)nstream * a.splits * d.M * d.C > d.scratch_floats))
+        return fail(SWF_ERR_WORKSPACE, "mlp_fused: scratch too small for %d hidden splits", a.splits);
+    switch (d.C) {
+        case 128: return launch_c<128>(a, nstream, stream);
+        case 192: return launch_c<192>(a, nstream, stream);
+        case 256: return launch_c<256>(a, nstream, stream);
+        case 384: return launch_c<384>(a, nstream, stream);
+    }
+    return fail(SWF_ERR_UNSUPPORTED, "mlp_fused: C=%d", d.C);
+}
+
+}  // namespace swf

@@ -11,6 +11,7 @@
 #include "kernels_window.h"
 #include "kernels_deep.h"
 #include "kernels_patch.h"
+#include "kernels_mlp.h"
 
 namespace swf {
 
@@ -220,7 +221,8 @@ static size_t deep_block_ws(const swf_block_desc* d, int nstream, int B, int H, 
         t += carve_bytes({(int64_t)deep_block_packed_bytes(*d) / 4});
         t += carve_bytes({N * C / 2, N * C / 2, N * HD, N * HD, N * HD, N * HD / 2, N * HD / 2, N * hid / 2, N * hid / 2});
     }
-    const int64_t sk = std::max((int64_t)gemm_sp_splitk_for((int)HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for((int)hid, SP_EPI_F32));
+    int64_t sk = std::max((int64_t)gemm_sp_splitk_for((int)HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for((int)hid, SP_EPI_F32));
+    if (mlp_fused_supported((int)C, (int)hid)) sk = std::max(sk, (int64_t)mlp_fused_splits((int)C, (int)hid));
     t += carve_bytes({sk > 1 ? sk * nstream * N * C : 0});
     return t;
 }
@@ -247,7 +249,10 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         o_hi[s] = planes(N * HD); o_lo[s] = planes(N * HD);
         h_hi[s] = planes(N * hid); h_lo[s] = planes(N * hid);
     }
-    const int64_t skn = std::max((int64_t)gemm_sp_splitk_for(HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for(hid, SP_EPI_F32));
+    int64_t skn = std::max((int64_t)gemm_sp_splitk_for(HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for(hid, SP_EPI_F32));
+    static const bool no_fused_mlp = std::getenv("SWF_NO_FUSED_MLP") != nullptr;   // A/B switch
+    const bool fused_mlp = !no_fused_mlp && mlp_fused_supported(C, hid) && N <= INT32_MAX / 2;
+    if (fused_mlp) skn = std::max(skn, (int64_t)mlp_fused_splits(C, hid));
     const int64_t sk_floats = skn > 1 ? skn * nstream * N * C : 0;
     float* sk = ws.floats(sk_floats);
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "deep block workspace too small (need %zu B)", ws.used);
@@ -286,6 +291,16 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         gp.p[s] = SpGemmProb{o_hi[s], o_lo[s], wv[s].p_hi, wv[s].p_lo, pp[s]->attn.proj.bias, xin[s], xout[s], nullptr, nullptr};
     SWF_TRY(launch_gemm_sp(gp, nstream, (int)N, C, HD, C, SP_EPI_F32, stream));
     // MLP half (a004:29-38 around a003:46-50)
+    if (fused_mlp) {   // LN2 + fc1 + ELU + fc2 + residual in one launch (+ a fixed-order reduce over the hidden splits)
+        MlpFusedDesc md{};
+        for (int s = 0; s < nstream; ++s) {
+            md.x[s] = xout[s]; md.out[s] = xout[s]; md.gamma[s] = pp[s]->ln2.gamma; md.beta[s] = pp[s]->ln2.beta;
+            md.w1_hi[s] = wv[s].w1f_hi; md.w1_lo[s] = wv[s].w1f_lo; md.w2_hi[s] = wv[s].w2f_hi; md.w2_lo[s] = wv[s].w2f_lo;
+            md.b1[s] = pp[s]->fc1.bias; md.b2[s] = pp[s]->fc2.bias;
+        }
+        md.scratch = sk; md.scratch_floats = sk_floats; md.M = (int)N; md.C = C; md.HID = hid;
+        return launch_mlp_fused(md, nstream, stream);
+    }
     LnBatch l2{};
     for (int s = 0; s < nstream; ++s) l2.p[s] = LnProb{xout[s], nullptr, pp[s]->ln2.gamma, pp[s]->ln2.beta, xn_hi[s], xn_lo[s]};
     SWF_TRY(launch_layernorm(l2, nstream, N, C, 0, stream));

@@ -218,8 +218,14 @@ _WIDE = [  # C, heads, d, hidden, (B,H,W), shift, cross
     (48, 8, 6, 96, (1, 24, 16), True, False),      # decoder width (hidden = in_dims * 4)
     (96, 8, 12, 384, (1, 16, 16), True, True),
     (96, 8, 12, 192, (2, 8, 16), False, True),
-    (192, 8, 24, 768, (1, 8, 8), True, True),       # unfused fast path: LN + split-K bf16x3 GEMMs + MFMA attention core
+    # deep-level fast path (kernels_deep / kernels_mlp): split-bf16 plane GEMMs, MFMA attention core, fused LN2+MLP kernel
+    (192, 8, 24, 768, (1, 8, 8), True, True),
     (384, 8, 48, 1536, (2, 8, 8), True, False),
+    (192, 8, 24, 384, (2, 8, 8), False, True),      # decoder widths (hidden = in_dims * 4): no hidden split / 3 splits
+    (384, 8, 48, 768, (1, 8, 8), True, True),
+    (192, 8, 24, 768, (2, 16, 16), True, False),    # several 64-token tiles per stream
+    (128, 4, 24, 512, (1, 8, 16), True, True),      # heads * d (96) != C: projection K = 96; fused MLP instantiation C = 128
+    (256, 8, 24, 1024, (1, 8, 8), False, False),    # heads * d = 192; fused MLP instantiation C = 256
 ]
 
 
