@@ -20,6 +20,13 @@
 #include <algorithm>
 #include <mutex>
 
+#ifndef SWF_C96_TT2
+#define SWF_C96_TT2 1   // C = 96 block kernel: 4 waves x 32 tokens, one wave per SIMD (106 -> 98 us, 79 -> 74 us)
+#endif
+#ifndef SWF_C48_TT2
+#define SWF_C48_TT2 1   // C = 48 block kernel: 32 tokens per wave (see window_block_kernel)
+#endif
+
 namespace swf {
 
 using bf16 = __bf16;
@@ -82,7 +89,7 @@ struct Geo {
 
 // L2-sourced weight fragments: stop hipcc from hoisting every iteration's global loads to the loop top (it would
 // spill); a compiler-only fence, no instruction.
-#define SWF_LOAD_FENCE(G_) do { if constexpr (!G_::WLDS) asm volatile("" ::: "memory"); } while (0)
+#define SWF_LOAD_FENCE(G_) do { if constexpr (!G_::WLDS && !ROOMY) asm volatile("" ::: "memory"); } while (0)
 
 struct WinArgs {
     const float* in[2];
@@ -200,10 +207,18 @@ __device__ __forceinline__ void layernorm_regs(const float4 (&res)[G::NTK], bf16
 // Wave w owns token rows [16*(w&3), +16) of stream w>>2 for every per-token phase (LN, projections, MLP):
 // those phases need no workgroup barrier.  Only attention mixes tokens: one barrier before, one after.
 // ------------------------------------------------------------------------------------------
-template <int C_, int HID_>
-__global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
+// TT = 16-token tiles per wave.  TT = 1: 512 threads, wave w owns tokens [16(w&3), +16) of stream w>>2.  TT = 2 (C = 48):
+// 256 threads, wave w owns tokens [32(w&1), +32) of stream w>>1: every weight fragment a wave pulls from L2 feeds two MFMAs
+// (half the L1->register traffic per token, the measured bound of the L2-sourced variants) and two workgroups share a CU.
+template <int C_, int HID_, int TT>
+__global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void window_block_kernel(WinArgs args) {
     using G = Geo<C_, HID_>;
     constexpr int C = G::C, D = G::D, T = G::T, LDC = G::LDC, KS = G::KC / 32;
+    constexpr int NTHR = 512 / TT;              // threads per workgroup
+    // Letting hipcc hoist the L2-sourced weight fragment loads where registers allow (C = 96, TT = 2: one wave per SIMD, 512
+    // registers; no fences, unroll 3) measured 127 us against 98 us fenced: the fences stay on for every L2-sourced variant.
+    constexpr bool ROOMY = false;
+    static_assert(TT == 1 || TT == 2, "one or two 16-token tiles per wave");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ahi = reinterpret_cast<bf16*>(smem + G::l_ahi);
     bf16* alo = reinterpret_cast<bf16*>(smem + G::l_alo);
@@ -227,16 +242,16 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
     {
         if constexpr (G::WLDS) {
             constexpr int W16 = G::wsec / 16;
-            for (int i = tid; i < 2 * W16; i += 512) {
+            for (int i = tid; i < 2 * W16; i += NTHR) {
                 const int s = i / W16, e = i % W16;
                 reinterpret_cast<uint4*>(smem + G::l_w + s * G::wsec)[e] = reinterpret_cast<const uint4*>(args.packed[s])[e];
             }
         }
         constexpr int Z16 = (G::l_vt - G::l_ahi) / 16;
         uint4* z = reinterpret_cast<uint4*>(smem + G::l_ahi);
-        for (int i = tid; i < Z16; i += 512) z[i] = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < G::VRS; i += 512) vt[G::ONES_ROW * G::VRS + i] = (f16)1.0f;
-        for (int i = tid; i < G::HEADS * G::NKS * 2; i += 512) {
+        for (int i = tid; i < Z16; i += NTHR) z[i] = make_uint4(0, 0, 0, 0);
+        for (int i = tid; i < G::VRS; i += NTHR) vt[G::ONES_ROW * G::VRS + i] = (f16)1.0f;
+        for (int i = tid; i < G::HEADS * G::NKS * 2; i += NTHR) {
             const int hf = i & 1, ks = (i >> 1) % G::NKS, head = i / (2 * G::NKS);
             unsigned m[4];
 #pragma unroll
@@ -250,26 +265,28 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
 
     // the wave's own 16 token rows live in registers for the whole block: lane (r16, g) holds, per 16-channel
     // tile nt, the 4 channels nt*16 + 4g .. +3 of token wm*16 + r16 (the MFMA output layout of the transposed tiles)
-    const int ws = wave >> 2, wm = wave & 3;           // stream and m-tile this wave owns
+    const int ws = wave / (4 / TT), wm0 = (wave % (4 / TT)) * TT;   // stream and first 16-token tile this wave owns
     const int r16 = lane & 15, g = lane >> 4;
     constexpr int NTK = G::NTK;
-    float4 res[NTK], pre[NTK];
-    auto token_base = [&](int win) -> int64_t {
+    float4 res[TT][NTK], pre[TT][NTK];
+    auto token_base = [&](int win, int tt) -> int64_t {
         const int b = win / (nwx * nwy), wrem = win % (nwx * nwy);
         const int wy = wrem / nwx, wx = wrem % nwx;
-        const int tok = wm * 16 + r16;
+        const int tok = (wm0 + tt) * 16 + r16;
         const int oy = (wy * G::WH + tok / G::WW + sh) % H, ox = (wx * G::WW + tok % G::WW + sw) % W;   // roll(-s): read at (y+s)%H
         return (((int64_t)b * H + oy) * W + ox) * C;
     };
 #define SWF_PREFETCH(WIN)                                                                                   \
     do {                                                                                                    \
-        const float* src_ = args.in[ws] + token_base(WIN);                                                  \
-        _Pragma("unroll") for (int nt = 0; nt < NTK; ++nt)                                                  \
-            pre[nt] = (nt * 16 + 4 * g < C) ? *reinterpret_cast<const float4*>(src_ + nt * 16 + 4 * g)      \
-                                            : make_float4(0.f, 0.f, 0.f, 0.f);                              \
+        _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) {                                                 \
+            const float* src_ = args.in[ws] + token_base(WIN, tt);                                          \
+            _Pragma("unroll") for (int nt = 0; nt < NTK; ++nt)                                              \
+                pre[tt][nt] = (nt * 16 + 4 * g < C) ? *reinterpret_cast<const float4*>(src_ + nt * 16 + 4 * g) \
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);                      \
+        }                                                                                                   \
     } while (0)
-    bf16* my_ahi = ahi + (ws * T + wm * 16) * LDC;
-    bf16* my_alo = alo + (ws * T + wm * 16) * LDC;
+    bf16* my_ahi = ahi + (ws * T + wm0 * 16) * LDC;   // tile tt of this wave: + tt * 16 * LDC
+    bf16* my_alo = alo + (ws * T + wm0 * 16) * LDC;
 
     int win = blockIdx.x;
     if (win < nwin) SWF_PREFETCH(win);
@@ -282,19 +299,24 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
         const int wy = wrem / nwx, wx = wrem % nwx;
         // ---- own rows: prefetched registers become the residual; start fetching the next window ----
 #pragma unroll
-        for (int nt = 0; nt < NTK; ++nt) res[nt] = pre[nt];
+        for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+            for (int nt = 0; nt < NTK; ++nt) res[tt][nt] = pre[tt][nt];
         if (win + (int)gridDim.x < nwin) SWF_PREFETCH(win + gridDim.x);
 
         // ---- LN1 -> A image (own rows) ----
-        layernorm_regs<G>(res, my_ahi, my_alo, wvec(ws), G::v_ln1g, G::v_ln1b, r16, g);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+            layernorm_regs<G>(res[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, wvec(ws), G::v_ln1g, G::v_ln1b, r16, g);
 
         // ---- Q, K, V projections of the own rows.  Q for the own stream; K and V for the stream whose attention
         //      reads these tokens as keys: itself, or the other one in a cross block (a002:67-82) ----
         {
-            Frag<KS> x;
-            load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
+            Frag<KS> x[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) load_frag<KS, LDC>(x[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, r16, g);
             const int kvs = args.cross ? 1 - ws : ws;
-            constexpr int NT_UNROLL = G::WLDS ? G::NTC : 1;   // see HC_UNROLL
+            constexpr int NT_UNROLL = G::WLDS ? G::NTC : (ROOMY ? 2 : 1);   // see HC_UNROLL
 #pragma unroll NT_UNROLL
             for (int nt = 0; nt < G::NTC; ++nt) {
                 const int ch4 = nt * 16 + 4 * g;           // this lane's 4 output channels (transposed tiles)
@@ -303,26 +325,30 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
                 load_frag<KS, G::KC>(wq, wmat(ws, G::p_wqkv_hi), wmat(ws, G::p_wqkv_lo), wrow, g);
                 load_frag<KS, G::KC>(wk, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), C + wrow, g);
                 load_frag<KS, G::KC>(wv, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), 2 * C + wrow, g);
-                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 aq = mma_bf16x3<KS>(wq, x, z4);   // [channel 4g+j][token r16]
-                const f32x4 ak = mma_bf16x3<KS>(wk, x, z4);
-                const f32x4 av = mma_bf16x3<KS>(x, wv, z4);   // [token 4g+j][channel r16]
-                if (ch4 < G::KC) {   // columns C..KC-1 are the K padding: rewritten as zeros (the MLP's hidden chunks reuse these rows)
-                    bf16x4 q4 = {0, 0, 0, 0}, k4 = {0, 0, 0, 0};
-                    if (ch4 < C) {
-                        const float4 bq = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bqkv + ch4);
-                        const float4 bk = *reinterpret_cast<const float4*>(wvec(kvs) + G::v_bqkv + C + ch4);
-                        q4 = bf16x4{(bf16)(aq[0] + bq.x), (bf16)(aq[1] + bq.y), (bf16)(aq[2] + bq.z), (bf16)(aq[3] + bq.w)};
-                        k4 = bf16x4{(bf16)(ak[0] + bk.x), (bf16)(ak[1] + bk.y), (bf16)(ak[2] + bk.z), (bf16)(ak[3] + bk.w)};
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const int trow = (wm0 + tt) * 16;          // first token row of this tile inside the window
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 aq = mma_bf16x3<KS>(wq, x[tt], z4);   // [channel 4g+j][token r16]
+                    const f32x4 ak = mma_bf16x3<KS>(wk, x[tt], z4);
+                    const f32x4 av = mma_bf16x3<KS>(x[tt], wv, z4);   // [token 4g+j][channel r16]
+                    if (ch4 < G::KC) {   // columns C..KC-1 are the K padding: rewritten as zeros (the MLP's hidden chunks reuse these rows)
+                        bf16x4 q4 = {0, 0, 0, 0}, k4 = {0, 0, 0, 0};
+                        if (ch4 < C) {
+                            const float4 bq = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bqkv + ch4);
+                            const float4 bk = *reinterpret_cast<const float4*>(wvec(kvs) + G::v_bqkv + C + ch4);
+                            q4 = bf16x4{(bf16)(aq[0] + bq.x), (bf16)(aq[1] + bq.y), (bf16)(aq[2] + bq.z), (bf16)(aq[3] + bq.w)};
+                            k4 = bf16x4{(bf16)(ak[0] + bk.x), (bf16)(ak[1] + bk.y), (bf16)(ak[2] + bk.z), (bf16)(ak[3] + bk.w)};
+                        }
+                        *reinterpret_cast<bf16x4*>(qimg + (ws * T + trow + r16) * LDC + ch4) = q4;
+                        *reinterpret_cast<bf16x4*>(kimg + (kvs * T + trow + r16) * LDC + ch4) = k4;
                     }
-                    *reinterpret_cast<bf16x4*>(qimg + (ws * T + wm * 16 + r16) * LDC + ch4) = q4;
-                    *reinterpret_cast<bf16x4*>(kimg + (kvs * T + wm * 16 + r16) * LDC + ch4) = k4;
-                }
-                const int chv = nt * 16 + r16;
-                if (chv < C) {
-                    const float bv = wvec(kvs)[G::v_bqkv + 2 * C + chv];
-                    f16x4 v4 = {(f16)(av[0] + bv), (f16)(av[1] + bv), (f16)(av[2] + bv), (f16)(av[3] + bv)};
-                    *reinterpret_cast<f16x4*>(vt + (kvs * C + chv) * G::VRS + vt_pos(wm * 16 + 4 * g)) = v4;
+                    const int chv = nt * 16 + r16;
+                    if (chv < C) {
+                        const float bv = wvec(kvs)[G::v_bqkv + 2 * C + chv];
+                        f16x4 v4 = {(f16)(av[0] + bv), (f16)(av[1] + bv), (f16)(av[2] + bv), (f16)(av[3] + bv)};
+                        *reinterpret_cast<f16x4*>(vt + (kvs * C + chv) * G::VRS + vt_pos(trow + 4 * g)) = v4;
+                    }
                 }
                 SWF_LOAD_FENCE(G);
             }
@@ -331,7 +357,8 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
 
         // ---- attention.  wave -> (stream, 32-query block, 4 heads) ----
         {
-            const int s = wave >> 2, qb = (wave >> 1) & 1, h0 = (wave & 1) * 4;
+            // TT = 1: wave -> (stream, 32-query block, 4 heads);  TT = 2: wave -> (stream, 32-query block), all 8 heads
+            const int s = ws, qb = TT == 1 ? (wave >> 1) & 1 : wave & 1, h0 = TT == 1 ? (wave & 1) * 4 : 0;
             const int r = lane & 31, hf = lane >> 5;
             const int variant = args.shift ? ((wy == nwy - 1) * 2 + (wx == nwx - 1)) : 0;
             if (variant != cur_variant) {   // wave-uniform; only edge windows of shifted blocks differ
@@ -347,7 +374,7 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
             const bf16* krow1 = krow0 + 32 * LDC;
             constexpr int HEAD_UNROLL = G::NTK <= 2 ? 2 : 1;   // two heads in flight while the residual registers are few
 #pragma unroll HEAD_UNROLL
-            for (int hh = 0; hh < 4; ++hh) {
+            for (int hh = 0; hh < 4 * TT; ++hh) {
                 const int head = h0 + hh;
                 // S^T = K . Qmasked^T: K rows carry all channels, the Q fragment is ANDed with the head's channel mask,
                 // so only the 16-deep k-steps that the head's channels touch are issued (1 or 2 for D <= 16).  The
@@ -436,41 +463,50 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
 
         // ---- output projection + residual (own rows; transposed tiles: a lane holds 4 channels of one token) ----
         {
-            Frag<KS> x;
-            load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
+            Frag<KS> x[TT];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt) load_frag<KS, LDC>(x[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, r16, g);
 #pragma unroll
             for (int nt = 0; nt < G::NTC; ++nt) {   // fully unrolled: res[] must be indexed statically
                 const int ch4 = nt * 16 + 4 * g;
                 Frag<KS> wp;
                 load_frag<KS, G::KC>(wp, wmat(ws, G::p_wp_hi), wmat(ws, G::p_wp_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g);
-                const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                const f32x4 acc = mma_bf16x3<KS>(wp, x, z4);
-                if (ch4 < C) {
-                    const float4 bp = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bp + ch4);
-                    res[nt].x += acc[0] + bp.x; res[nt].y += acc[1] + bp.y; res[nt].z += acc[2] + bp.z; res[nt].w += acc[3] + bp.w;
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) {
+                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                    const f32x4 acc = mma_bf16x3<KS>(wp, x[tt], z4);
+                    if (ch4 < C) {
+                        const float4 bp = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bp + ch4);
+                        res[tt][nt].x += acc[0] + bp.x; res[tt][nt].y += acc[1] + bp.y; res[tt][nt].z += acc[2] + bp.z; res[tt][nt].w += acc[3] + bp.w;
+                    }
                 }
                 SWF_LOAD_FENCE(G);
             }
         }
 
         // ---- LN2 -> A image (own rows) ----
-        layernorm_regs<G>(res, my_ahi, my_alo, wvec(ws), G::v_ln2g, G::v_ln2b, r16, g);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt)
+            layernorm_regs<G>(res[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, wvec(ws), G::v_ln2g, G::v_ln2b, r16, g);
 
         // ---- MLP, own rows, walking the hidden dimension in chunks of 32: fc1 + ELU for the chunk -> split-bf16
         //      image over the wave's own A rows (xn2 already sits in registers) -> one k-step of fc2.  The hidden
         //      activations never exist as a whole. ----
         {
-            Frag<KS> x;
-            load_frag<KS, LDC>(x, my_ahi, my_alo, r16, g);
-            f32x4 out[G::NTC];
+            Frag<KS> x[TT];
 #pragma unroll
-            for (int nt = 0; nt < G::NTC; ++nt) out[nt] = f32x4{0.f, 0.f, 0.f, 0.f};
+            for (int tt = 0; tt < TT; ++tt) load_frag<KS, LDC>(x[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, r16, g);
+            f32x4 out[TT][G::NTC];
+#pragma unroll
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int nt = 0; nt < G::NTC; ++nt) out[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
             // two chunk buffers so consecutive chunks do not serialise on one LDS region: the wave's A rows, and
             // the Q / K rows it wrote for this window (dead since the post-attention barrier; the projections of
             // the next window rewrite them, K padding included)
-            bf16* hb_hi[2] = {my_ahi, qimg + (ws * T + wm * 16) * LDC};
-            bf16* hb_lo[2] = {my_alo, kimg + ((args.cross ? 1 - ws : ws) * T + wm * 16) * LDC};
-            constexpr int HC_UNROLL = G::WLDS ? G::KH / 32 : 2;   // L2-sourced weights: full unrolling hoists every fragment load and spills
+            bf16* hb_hi[2] = {my_ahi, qimg + (ws * T + wm0 * 16) * LDC};
+            bf16* hb_lo[2] = {my_alo, kimg + ((args.cross ? 1 - ws : ws) * T + wm0 * 16) * LDC};
+            constexpr int HC_UNROLL = G::WLDS ? G::KH / 32 : (ROOMY ? 3 : 2);   // L2-sourced weights: full unrolling hoists every fragment load and spills
 #pragma unroll HC_UNROLL
             for (int hc = 0; hc < G::KH / 32; ++hc) {
                 bf16* hhi = hb_hi[hc & 1];
@@ -478,48 +514,64 @@ __global__ __launch_bounds__(512, 2) void window_block_kernel(WinArgs args) {
 #pragma unroll
                 for (int t2 = 0; t2 < 2; ++t2) {
                     const int hid0 = hc * 32 + t2 * 16;
-                    bf16x4 h4 = {0, 0, 0, 0}, l4 = {0, 0, 0, 0};
                     if (hid0 < G::HID) {   // compile-time: tiles wholly in the K padding are just zeros
                         Frag<KS> w1;
                         load_frag<KS, G::KC>(w1, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hid0 + r16 < G::HID ? hid0 + r16 : 0, g);
-                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                        const f32x4 acc = mma_bf16x3<KS>(w1, x, z4);   // [hidden 4g+j][token r16]
                         const float4 b1 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hid0 + 4 * g);
-                        float v[4] = {acc[0] + b1.x, acc[1] + b1.y, acc[2] + b1.z, acc[3] + b1.w};
 #pragma unroll
-                        for (int j = 0; j < 4; ++j) v[j] = (hid0 + 4 * g + j < G::HID) ? elu_fast(v[j]) : 0.f;
-                        split4_bf16(v, h4, l4);
+                        for (int tt = 0; tt < TT; ++tt) {
+                            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                            const f32x4 acc = mma_bf16x3<KS>(w1, x[tt], z4);   // [hidden 4g+j][token r16]
+                            float v[4] = {acc[0] + b1.x, acc[1] + b1.y, acc[2] + b1.z, acc[3] + b1.w};
+#pragma unroll
+                            for (int j = 0; j < 4; ++j) v[j] = (hid0 + 4 * g + j < G::HID) ? elu_fast(v[j]) : 0.f;
+                            bf16x4 h4, l4;
+                            split4_bf16(v, h4, l4);
+                            *reinterpret_cast<bf16x4*>(hhi + (tt * 16 + r16) * LDC + t2 * 16 + 4 * g) = h4;
+                            *reinterpret_cast<bf16x4*>(hlo + (tt * 16 + r16) * LDC + t2 * 16 + 4 * g) = l4;
+                        }
+                    } else {
+                        const bf16x4 z = {0, 0, 0, 0};
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) {
+                            *reinterpret_cast<bf16x4*>(hhi + (tt * 16 + r16) * LDC + t2 * 16 + 4 * g) = z;
+                            *reinterpret_cast<bf16x4*>(hlo + (tt * 16 + r16) * LDC + t2 * 16 + 4 * g) = z;
+                        }
                     }
-                    *reinterpret_cast<bf16x4*>(hhi + r16 * LDC + t2 * 16 + 4 * g) = h4;
-                    *reinterpret_cast<bf16x4*>(hlo + r16 * LDC + t2 * 16 + 4 * g) = l4;
                     SWF_LOAD_FENCE(G);
                 }
-                Frag<1> hfrag;
-                load_frag<1, LDC>(hfrag, hhi, hlo, r16, g);
+                Frag<1> hfrag[TT];
+#pragma unroll
+                for (int tt = 0; tt < TT; ++tt) load_frag<1, LDC>(hfrag[tt], hhi + tt * 16 * LDC, hlo + tt * 16 * LDC, r16, g);
 #pragma unroll
                 for (int nt = 0; nt < G::NTC; ++nt) {
                     Frag<1> w2;
                     load_frag<1, G::KH>(w2, wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
-                    out[nt] = mma_bf16x3<1>(w2, hfrag, out[nt]);
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) out[tt][nt] = mma_bf16x3<1>(w2, hfrag[tt], out[tt][nt]);
                     if ((nt & 1) == 1) SWF_LOAD_FENCE(G);
                 }
             }
 #pragma unroll
-            for (int nt = 0; nt < G::NTC; ++nt) {
-                const int ch4 = nt * 16 + 4 * g;
-                if (ch4 < C) {
-                    const float4 b2 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b2 + ch4);
-                    res[nt].x += out[nt][0] + b2.x; res[nt].y += out[nt][1] + b2.y; res[nt].z += out[nt][2] + b2.z; res[nt].w += out[nt][3] + b2.w;
+            for (int tt = 0; tt < TT; ++tt)
+#pragma unroll
+                for (int nt = 0; nt < G::NTC; ++nt) {
+                    const int ch4 = nt * 16 + 4 * g;
+                    if (ch4 < C) {
+                        const float4 b2 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b2 + ch4);
+                        res[tt][nt].x += out[tt][nt][0] + b2.x; res[tt][nt].y += out[tt][nt][1] + b2.y;
+                        res[tt][nt].z += out[tt][nt][2] + b2.z; res[tt][nt].w += out[tt][nt][3] + b2.w;
+                    }
                 }
-            }
         }
 
         // ---- store the own rows (un-shift = same index map as the load) ----
-        {
-            float* dst = args.out[ws] + token_base(win);
+#pragma unroll
+        for (int tt = 0; tt < TT; ++tt) {
+            float* dst = args.out[ws] + token_base(win, tt);
 #pragma unroll
             for (int nt = 0; nt < NTK; ++nt)
-                if (nt * 16 + 4 * g < C) *reinterpret_cast<float4*>(dst + nt * 16 + 4 * g) = res[nt];
+                if (nt * 16 + 4 * g < C) *reinterpret_cast<float4*>(dst + nt * 16 + 4 * g) = res[tt][nt];
         }
     }
 #undef SWF_PREFETCH
@@ -1045,14 +1097,16 @@ static int num_cus() {
 template <int C, int HID>
 static int launch_t(const WinArgs& a, int nwin, hipStream_t stream) {
     using G = Geo<C, HID>;
+    // C = 48: two 16-token tiles per wave, 256-thread workgroups, two per CU (67 KB of LDS each)
+    constexpr int TT = ((C == 48 && HID == 192 && SWF_C48_TT2) || (C == 96 && SWF_C96_TT2)) ? 2 : 1;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_block_kernel<C, HID>),
+        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_block_kernel<C, HID, TT>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::l_total);
     });
     if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window_block): %s", hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((window_block_kernel<C, HID>), dim3(std::min(nwin, num_cus())), dim3(512), G::l_total, stream, a);
+    hipLaunchKernelGGL((window_block_kernel<C, HID, TT>), dim3(std::min(nwin, TT * num_cus())), dim3(512 / TT), G::l_total, stream, a);
     return check_launch("window_block");
 }
 
