@@ -20,6 +20,9 @@
 #include <algorithm>
 #include <mutex>
 
+#ifndef SWF_MLP_ROTATE
+#define SWF_MLP_ROTATE 1
+#endif
 #ifndef SWF_C96_TT2
 #define SWF_C96_TT2 1   // C = 96 block kernel: 4 waves x 32 tokens, one wave per SIMD (106 -> 98 us, 79 -> 74 us)
 #endif
@@ -83,7 +86,10 @@ struct Geo {
     static constexpr int ONES_ROW = 2 * C;                                // extra V^T row of 1.0: its product with P^T is the softmax denominator
     static constexpr size_t l_mask = l_vt + size_t(2 * C + 1) * VRS * 2;  // [8 heads][NKS][2 lane halves] x 16 B: channel masks of a head
     static constexpr size_t l_w = (l_mask + size_t(HEADS) * NKS * 2 * 16 + 15) / 16 * 16;   // the two streams' weight sections
-    static constexpr size_t l_total = l_w + (WLDS ? 2 * wsec : 0);
+    // L2-sourced weights: the fp32 vectors (LN gamma / beta, biases) of both streams are still staged into LDS — every one
+    // of their loads would otherwise expose an L2 round trip (one wave per SIMD at C = 96 hides nothing)
+    static constexpr size_t vsec = (size_t(v_end) * 4 + 15) / 16 * 16;
+    static constexpr size_t l_total = l_w + (WLDS ? 2 * wsec : 2 * vsec);
     static_assert(l_total <= 160 * 1024, "window tile (+ weights) exceed the 160 KiB LDS of a CU");
 };
 
@@ -235,7 +241,9 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
 
     auto wsec = [&](int s) -> const char* { return G::WLDS ? smem + G::l_w + s * G::wsec : args.packed[s]; };
     auto wmat = [&](int s, size_t off) { return reinterpret_cast<const bf16*>(wsec(s) + off); };
-    auto wvec = [&](int s) { return reinterpret_cast<const float*>(wsec(s) + G::p_vec); };
+    auto wvec = [&](int s) {
+        return G::WLDS ? reinterpret_cast<const float*>(smem + G::l_w + s * G::wsec + G::p_vec) : reinterpret_cast<const float*>(smem + G::l_w + s * G::vsec);
+    };
 
     // ---- once per workgroup: weights -> LDS, zero the images (the K padding of Q / K rows is never written
     //      again and must read as exact zeros), build the per-head channel masks ----
@@ -245,6 +253,12 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             for (int i = tid; i < 2 * W16; i += NTHR) {
                 const int s = i / W16, e = i % W16;
                 reinterpret_cast<uint4*>(smem + G::l_w + s * G::wsec)[e] = reinterpret_cast<const uint4*>(args.packed[s])[e];
+            }
+        }
+        if constexpr (!G::WLDS) {
+            for (int i = tid; i < 2 * G::v_end; i += NTHR) {
+                const int s = i / G::v_end, e = i % G::v_end;
+                reinterpret_cast<float*>(smem + G::l_w + s * G::vsec)[e] = reinterpret_cast<const float*>(args.packed[s] + G::p_vec)[e];
             }
         }
         constexpr int Z16 = (G::l_vt - G::l_ahi) / 16;
@@ -484,6 +498,35 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             }
         }
 
+        // Rotating-register MLP weights (C = 96, TT = 2: one wave per SIMD, nothing else hides an L2 round trip, and 512
+        // registers to spend): the fc1 fragments (+ bias) of chunk hc+1 are requested as soon as chunk hc's fc1 MFMAs have
+        // consumed theirs, the fc2 fragments of chunk hc+1 as soon as chunk hc's fc2 MFMAs have; chunk 0's go out here, under
+        // LN2.  Scheduling fences pin the issue points (hipcc otherwise sinks the loads next to their uses).
+        constexpr bool ROT = !G::WLDS && TT == 2 && C_ == 96 && SWF_MLP_ROTATE && G::HID % 32 == 0;
+        Frag<ROT ? KS : 1> w1a, w1b;
+        Frag<1> w2r[ROT ? G::NTC : 1];
+        float4 b1a, b1b;
+        auto req_fc1 = [&](int hc) {
+            if constexpr (ROT) {
+                b1a = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hc * 32 + 4 * g);
+                b1b = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hc * 32 + 16 + 4 * g);
+                load_frag<KS, G::KC>(w1a, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hc * 32 + r16, g);
+                load_frag<KS, G::KC>(w1b, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hc * 32 + 16 + r16, g);
+            }
+        };
+        auto req_fc2 = [&](int hc) {
+            if constexpr (ROT) {
+#pragma unroll
+                for (int nt = 0; nt < G::NTC; ++nt)
+                    load_frag<1, G::KH>(w2r[nt], wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
+            }
+        };
+        if constexpr (ROT) {
+            req_fc1(0);
+            req_fc2(0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+
         // ---- LN2 -> A image (own rows) ----
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
@@ -506,6 +549,7 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             // the next window rewrite them, K padding included)
             bf16* hb_hi[2] = {my_ahi, qimg + (ws * T + wm0 * 16) * LDC};
             bf16* hb_lo[2] = {my_alo, kimg + ((args.cross ? 1 - ws : ws) * T + wm0 * 16) * LDC};
+            if constexpr (!ROT) {
             constexpr int HC_UNROLL = G::WLDS ? G::KH / 32 : (ROOMY ? 3 : 2);   // L2-sourced weights: full unrolling hoists every fragment load and spills
 #pragma unroll HC_UNROLL
             for (int hc = 0; hc < G::KH / 32; ++hc) {
@@ -550,6 +594,49 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
 #pragma unroll
                     for (int tt = 0; tt < TT; ++tt) out[tt][nt] = mma_bf16x3<1>(w2, hfrag[tt], out[tt][nt]);
                     if ((nt & 1) == 1) SWF_LOAD_FENCE(G);
+                }
+            }
+            } else {
+                constexpr int NCH = G::KH / 32;
+                static_assert(NCH % 2 == 0, "rotating MLP path is unrolled by two chunks");
+#pragma unroll 2
+                for (int hc = 0; hc < NCH; ++hc) {
+                    bf16* hhi = hb_hi[hc & 1];
+                    bf16* hlo = hb_lo[hc & 1];
+                    const int hcn = hc + 1 < NCH ? hc + 1 : hc;   // past the last chunk: dead re-loads instead of a branch
+                    f32x4 acc_a[TT], acc_b[TT];
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) {
+                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+                        acc_a[tt] = mma_bf16x3<KS>(w1a, x[tt], z4);   // [hidden 4g+j][token r16]
+                        acc_b[tt] = mma_bf16x3<KS>(w1b, x[tt], z4);
+                    }
+                    const float4 ba = b1a, bb = b1b;
+                    __builtin_amdgcn_sched_barrier(0);
+                    req_fc1(hcn);
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) {
+                        float va[4] = {elu_fast(acc_a[tt][0] + ba.x), elu_fast(acc_a[tt][1] + ba.y), elu_fast(acc_a[tt][2] + ba.z), elu_fast(acc_a[tt][3] + ba.w)};
+                        float vb[4] = {elu_fast(acc_b[tt][0] + bb.x), elu_fast(acc_b[tt][1] + bb.y), elu_fast(acc_b[tt][2] + bb.z), elu_fast(acc_b[tt][3] + bb.w)};
+                        bf16x4 h4, l4;
+                        split4_bf16(va, h4, l4);
+                        *reinterpret_cast<bf16x4*>(hhi + (tt * 16 + r16) * LDC + 4 * g) = h4;
+                        *reinterpret_cast<bf16x4*>(hlo + (tt * 16 + r16) * LDC + 4 * g) = l4;
+                        split4_bf16(vb, h4, l4);
+                        *reinterpret_cast<bf16x4*>(hhi + (tt * 16 + r16) * LDC + 16 + 4 * g) = h4;
+                        *reinterpret_cast<bf16x4*>(hlo + (tt * 16 + r16) * LDC + 16 + 4 * g) = l4;
+                    }
+                    Frag<1> hfrag[TT];
+#pragma unroll
+                    for (int tt = 0; tt < TT; ++tt) load_frag<1, LDC>(hfrag[tt], hhi + tt * 16 * LDC, hlo + tt * 16 * LDC, r16, g);
+#pragma unroll
+                    for (int nt = 0; nt < G::NTC; ++nt)
+#pragma unroll
+                        for (int tt = 0; tt < TT; ++tt) out[tt][nt] = mma_bf16x3<1>(w2r[nt], hfrag[tt], out[tt][nt]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    req_fc2(hcn);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
             }
 #pragma unroll
