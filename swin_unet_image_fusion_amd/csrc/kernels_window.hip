@@ -1185,7 +1185,7 @@ template <int C, int HID>
 static int launch_t(const WinArgs& a, int nwin, hipStream_t stream) {
     using G = Geo<C, HID>;
     // C = 48: two 16-token tiles per wave, 256-thread workgroups, two per CU (67 KB of LDS each)
-    constexpr int TT = ((C == 48 && HID == 192 && SWF_C48_TT2) || (C == 96 && SWF_C96_TT2)) ? 2 : 1;
+    constexpr int TT = ((C == 48 && SWF_C48_TT2) || (C == 96 && SWF_C96_TT2)) ? 2 : 1;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
