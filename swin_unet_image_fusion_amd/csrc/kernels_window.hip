@@ -1,9 +1,12 @@
 // Fused fast tier for gfx950 (MI355X): ONE launch = one BasicBlock (a005:127-145) for both modality
-// streams, for 8x8 windows and C in {24, 48, 96}.  Persistent: one 512-thread workgroup per CU (8 waves,
-// 2 per SIMD) walks the windows.  Wave w owns 16 token rows of stream w>>2 for every per-token phase
-// (LN1, Q/K/V, proj, LN2, MLP): its residual rows live in registers in the MFMA output layout, it loads them
-// once from HBM (cyclic shift = index arithmetic) and stores them once.  Only attention mixes tokens and needs
-// the two workgroup barriers per window.  HBM traffic per block = read + write of each stream, nothing else.
+// streams, for 8x8 windows and C in {24, 48, 96}.  Persistent workgroups walk the windows.  C = 24: 512 threads
+// (8 waves, 2 per SIMD), one workgroup per CU, weights resident in LDS, wave w owns 16 token rows of stream w>>2.
+// C = 48 / 96 (TT = 2): 256 threads, wave w owns 32 token rows of stream w>>1, weights come from L2 and every
+// fragment feeds two MFMAs; two workgroups per CU at C = 48, one (one wave per SIMD, 512 registers, rotating MLP
+// weight prefetch) at C = 96.  A wave keeps its rows for every per-token phase (LN1, Q/K/V, proj, LN2, MLP): the
+// residual rows live in registers in the MFMA output layout, loaded once from HBM (cyclic shift = index arithmetic)
+// and stored once.  Only attention mixes tokens and needs the two workgroup barriers per window.  HBM traffic per
+// block = read + write of each stream, nothing else.
 //
 // Arithmetic (include/swinfuse.h SWF_PREC_FAST; error budget measured in DESIGN.md):
 //   linear layers : split-bf16 "bf16x3" on v_mfma_f32_16x16x32_bf16 — a = a_hi + a_lo, w = w_hi + w_lo,
