@@ -14,6 +14,7 @@
 #include "kernels_mlp.h"
 
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 
 #ifndef SWF_GEMM_ABL
@@ -271,12 +272,13 @@ template <int WM, int WN>
 static int launch_sp_cfg(dim3 grid, hipStream_t stream, const SpBatchDev& dev, int M, int N, int K, int ldo, int epi, int splitk,
                          int kchunk) {
     constexpr int lds_bytes = 2 * (2 * 64 * WM * 64 + 2 * 64 * WN * 64);   // two stages
-    static bool attr_done = false;   // > 64 KB of dynamic LDS needs the attribute once per kernel
-    if (!attr_done && lds_bytes > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                lds_bytes) != hipSuccess)
-            return fail(SWF_ERR_HIP, "gemm_sp: cannot raise the dynamic LDS limit to %d B", lds_bytes);
-        attr_done = true;
+    static std::once_flag once;   // > 64 KB of dynamic LDS needs the attribute once per kernel (thread-safe)
+    static hipError_t attr_err = hipSuccess;
+    if (lds_bytes > 65536) {
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_sp_kernel<WM, WN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+        });
+        if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "gemm_sp: cannot raise the dynamic LDS limit to %d B", lds_bytes);
     }
     hipLaunchKernelGGL((gemm_sp_kernel<WM, WN>), grid, dim3(256), lds_bytes, stream, dev, M, N, K, ldo, epi, splitk, kchunk);
     return SWF_OK;

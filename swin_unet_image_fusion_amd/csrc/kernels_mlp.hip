@@ -19,6 +19,7 @@
 #include "kernels_mlp.h"
 
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 
 namespace swf {
@@ -302,11 +303,13 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(MlpArgs a, int C) {
 template <int C>
 int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
     constexpr int lds = (64 * (C + 8) + 64 * (128 + 8)) * 2 * 2;
-    static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return fail(SWF_ERR_HIP, "mlp_fused: cannot raise the dynamic LDS limit to %d B", lds);
-        attr_done = true;
+    static std::once_flag once;   // > 64 KB of dynamic LDS needs the attribute once per kernel (thread-safe)
+    static hipError_t attr_err = hipSuccess;
+    if (lds > 65536) {
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        });
+        if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "mlp_fused: cannot raise the dynamic LDS limit to %d B", lds);
     }
     dim3 grid((a.M + 63) / 64, a.splits, nstream);
     hipLaunchKernelGGL((mlp_fused_kernel<C>), grid, dim3(256), lds, stream, a);

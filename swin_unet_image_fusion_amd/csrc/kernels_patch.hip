@@ -10,6 +10,7 @@
 #include "kernels_patch.h"
 
 #include <algorithm>
+#include <mutex>
 #include <cstdlib>
 
 namespace swf {
@@ -270,12 +271,13 @@ template <int KS, int NT, int DEC, int VEC>
 int launch_cfg(const PatchArgs& a, int nstream, hipStream_t stream) {
     constexpr int KP = 32 * KS + 8;
     constexpr int lds = (16 * NT + 64) * KP * 2 * 2 + 3 * 16 * NT * 4;
-    static bool attr_done = false;
-    if (!attr_done && lds > 65536) {
-        if (hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_fused_kernel<KS, NT, DEC, VEC>),
-                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)
-            return fail(SWF_ERR_HIP, "patch_fused: cannot raise the dynamic LDS limit to %d B", lds);
-        attr_done = true;
+    static std::once_flag once;   // > 64 KB of dynamic LDS needs the attribute once per kernel (thread-safe)
+    static hipError_t attr_err = hipSuccess;
+    if (lds > 65536) {
+        std::call_once(once, [] {
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&patch_fused_kernel<KS, NT, DEC, VEC>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        });
+        if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "patch_fused: cannot raise the dynamic LDS limit to %d B", lds);
     }
     const int ntiles = (a.M + 63) / 64;
     // a few tiles per workgroup amortise the weight staging; at most ~8 resident workgroups per CU
