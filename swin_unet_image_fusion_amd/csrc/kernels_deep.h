@@ -22,8 +22,11 @@ struct SpGemmBatch {
     SpGemmProb p[kMaxProb];
     float* scratch = nullptr;          // split-K partials (only used when K >= kSpSplitKMinK)
     int64_t scratch_floats = 0;
+    float qscale = 1.0f;               // SP_EPI_QKV16
 };
-enum { SP_EPI_F32 = 0, SP_EPI_ELU_SPLIT = 1 };
+// SP_EPI_QKV16: the operands of the attention core in their final formats, written to o_hi [M][N] (16-bit elements):
+// problem p % 3 == 0 -> bf16((acc + bias) * batch.qscale) (Q, scale = d^-0.5 * log2 e), == 1 -> bf16 (K), == 2 -> fp16 (V)
+enum { SP_EPI_F32 = 0, SP_EPI_ELU_SPLIT = 1, SP_EPI_QKV16 = 2 };
 
 bool gemm_sp_supported(int N, int K);
 // K slices as a function of K alone (batch shards must stay bit-identical): floats of scratch = slices*nprob*M*N

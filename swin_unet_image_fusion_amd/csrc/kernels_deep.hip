@@ -47,7 +47,7 @@ struct SpProbDev {
     const bf16* a_hi; const bf16* a_lo; const bf16* w_hi; const bf16* w_lo;
     const float* bias; const float* res; float* out; bf16* o_hi; bf16* o_lo;
 };
-struct SpBatchDev { SpProbDev p[kMaxProb]; float* scratch; };
+struct SpBatchDev { SpProbDev p[kMaxProb]; float* scratch; float qscale; };
 
 }  // namespace
 
@@ -193,7 +193,18 @@ __global__ __launch_bounds__(256) void gemm_sp_kernel(SpBatchDev batch, int M, i
                 const float4 b = *reinterpret_cast<const float4*>(pr.bias + n);
                 v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
             }
-            if (epi == SP_EPI_ELU_SPLIT) {
+            if (epi == SP_EPI_QKV16) {
+                const int which = prob % 3;
+                if (which == 2) {
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+                    const f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
+                    *reinterpret_cast<f16x4*>(pr.o_hi + (int64_t)m * N + n) = h;
+                } else {
+                    const float sc = which == 0 ? batch.qscale : 1.0f;
+                    const bf16x4 h = {(bf16)(v.x * sc), (bf16)(v.y * sc), (bf16)(v.z * sc), (bf16)(v.w * sc)};
+                    *reinterpret_cast<bf16x4*>(pr.o_hi + (int64_t)m * N + n) = h;
+                }
+            } else if (epi == SP_EPI_ELU_SPLIT) {
                 v.x = elu_1(v.x); v.y = elu_1(v.y); v.z = elu_1(v.z); v.w = elu_1(v.w);
                 bf16x4 hi, lo;
                 split_f4(v, hi, lo);
@@ -296,6 +307,7 @@ int launch_gemm_sp(const SpGemmBatch& batch, int nprob, int M, int N, int K, int
                              s.bias, s.res, s.out, reinterpret_cast<bf16*>(s.o_hi), reinterpret_cast<bf16*>(s.o_lo)};
     }
     dev.scratch = batch.scratch;
+    dev.qscale = batch.qscale;
     const int splitk = gemm_sp_splitk_for(K, epi);
     if (splitk > 1 && (!batch.scratch || (int64_t)splitk * nprob * M * N > batch.scratch_floats))
         return fail(SWF_ERR_WORKSPACE, "gemm_sp: split-K scratch too small (%d slices of %d x %d x %d)", splitk, nprob, M, N);

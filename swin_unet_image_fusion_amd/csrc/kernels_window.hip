@@ -23,6 +23,9 @@
 #include <algorithm>
 #include <mutex>
 
+#ifndef SWF_HEAD_UNROLL_C24
+#define SWF_HEAD_UNROLL_C24 2
+#endif
 #ifndef SWF_MLP_ROTATE
 #define SWF_MLP_ROTATE 1
 #endif
@@ -389,7 +392,7 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             const bf16* qrow = qimg + (s * T + 32 * qb + r) * LDC + 8 * hf;
             const bf16* krow0 = kimg + (s * T + r) * LDC + 8 * hf;
             const bf16* krow1 = krow0 + 32 * LDC;
-            constexpr int HEAD_UNROLL = G::NTK <= 2 ? 2 : 1;   // two heads in flight while the residual registers are few
+            constexpr int HEAD_UNROLL = G::NTK <= 2 ? SWF_HEAD_UNROLL_C24 : 1;   // heads in flight while the residual registers are few
 #pragma unroll HEAD_UNROLL
             for (int hh = 0; hh < 4 * TT; ++hh) {
                 const int head = h0 + hh;
@@ -676,6 +679,7 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
 struct AttnMfmaArgs {
     const float* Q[2]; const float* K[2]; const float* V[2]; float* O[2]; const float* table[2];
     unsigned short* Ohi[2]; unsigned short* Olo[2];   // non-null: O is written as split-bf16 planes (row stride ldo) instead
+    const unsigned short* Q16[2]; const unsigned short* K16[2]; const unsigned short* V16[2];   // non-null: Q (pre-scaled bf16), K (bf16), V (fp16)
     int ldq, ldk, ldv, ldo, B, H, W, heads, shift;
 };
 
@@ -705,6 +709,38 @@ __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
             kimg[tok * QS + c] = (bf16)0.f;
         }
     }
+    if constexpr (VEC == 4) {
+        if (a.Q16[p]) {   // operands already in their final 16-bit formats (deep-level Q/K/V GEMM epilogue): plain copies
+            uint2 q2[NIT], k2[NIT], v2[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + it * 128;
+                if (e < NCHUNK) {
+                    const int tok = e / CPT, c0 = (e % CPT) * VEC;
+                    const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
+                    const int64_t t = ((int64_t)b * H + oy) * W + ox;
+                    q2[it] = *reinterpret_cast<const uint2*>(a.Q16[p] + t * a.ldq + head * D + c0);
+                    k2[it] = *reinterpret_cast<const uint2*>(a.K16[p] + t * a.ldk + head * D + c0);
+                    v2[it] = *reinterpret_cast<const uint2*>(a.V16[p] + t * a.ldv + head * D + c0);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + it * 128;
+                if (e < NCHUNK) {
+                    const int tok = e / CPT, c0 = (e % CPT) * VEC;
+                    const int vp = vt_pos(tok);
+                    *reinterpret_cast<uint2*>(qimg + tok * QS + c0) = q2[it];
+                    *reinterpret_cast<uint2*>(kimg + tok * QS + c0) = k2[it];
+                    const f16x4 v4 = __builtin_bit_cast(f16x4, v2[it]);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) vt[(c0 + j) * VRS + vp] = v4[j];
+                }
+            }
+            goto staged;
+        }
+    }
+    {
     // Q / K / V of this head -> LDS images; all loads of a thread are issued before the first conversion
     float qv[NIT][VEC], kv[NIT][VEC], vv[NIT][VEC];
 #pragma unroll
@@ -744,6 +780,8 @@ __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
             }
         }
     }
+    }
+staged:
     __syncthreads();
 
     const int r = lane & 31, hf = lane >> 5;
@@ -1076,11 +1114,14 @@ bool attn_core_mfma_supported(int wh, int ww, int head_dim) {
 int launch_attn_core_mfma(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
                           const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
                           int heads, int head_dim, int shift, hipStream_t stream, unsigned short* const* O_hi,
-                          unsigned short* const* O_lo) {
+                          unsigned short* const* O_lo, const unsigned short* const* Q16, const unsigned short* const* K16,
+                          const unsigned short* const* V16) {
     AttnMfmaArgs a{};
+    if (Q16 && (head_dim % 4 || ldq % 4 || ldk % 4 || ldv % 4)) return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: 16-bit operands need head_dim and strides %% 4 == 0");
     if (O_hi && head_dim % 4) return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: split-plane output needs head_dim %% 4 == 0");
     for (int i = 0; i < nprob; ++i) {
-        a.Q[i] = Q[i]; a.K[i] = K[i]; a.V[i] = V[i]; a.O[i] = O ? O[i] : nullptr; a.table[i] = table[i];
+        a.Q[i] = Q ? Q[i] : nullptr; a.K[i] = K ? K[i] : nullptr; a.V[i] = V ? V[i] : nullptr; a.O[i] = O ? O[i] : nullptr; a.table[i] = table[i];
+        a.Q16[i] = Q16 ? Q16[i] : nullptr; a.K16[i] = Q16 ? K16[i] : nullptr; a.V16[i] = Q16 ? V16[i] : nullptr;
         a.Ohi[i] = O_hi ? O_hi[i] : nullptr; a.Olo[i] = O_hi ? O_lo[i] : nullptr;
     }
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.W = W; a.heads = heads; a.shift = shift;

@@ -2,6 +2,7 @@
 // of kernels into the reference's units (WindowAttention, BasicBlock halves, SelfAndCrossBlockPair,
 // PatchMergingAndLinearLayer + MyPadding, final head, MyModel.forward).
 #include <algorithm>
+#include <cmath>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -219,7 +220,7 @@ static size_t deep_block_ws(const swf_block_desc* d, int nstream, int B, int H, 
     size_t t = 0;
     for (int s = 0; s < nstream; ++s) {
         t += carve_bytes({(int64_t)deep_block_packed_bytes(*d) / 4});
-        t += carve_bytes({N * C / 2, N * C / 2, N * HD, N * HD, N * HD, N * HD / 2, N * HD / 2, N * hid / 2, N * hid / 2});
+        t += carve_bytes({N * C / 2, N * C / 2, N * HD / 2, N * HD / 2, N * HD / 2, N * HD / 2, N * HD / 2, N * hid / 2, N * hid / 2});
     }
     int64_t sk = std::max((int64_t)gemm_sp_splitk_for((int)HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for((int)hid, SP_EPI_F32));
     if (mlp_fused_supported((int)C, (int)hid)) sk = std::max(sk, (int64_t)mlp_fused_splits((int)C, (int)hid));
@@ -240,12 +241,12 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
     const void* pk[2] = {packed_x, packed_y};
     auto planes = [&](int64_t n) { return reinterpret_cast<bf16_raw*>(ws.floats(n / 2)); };
     bf16_raw *xn_hi[2], *xn_lo[2], *o_hi[2], *o_lo[2], *h_hi[2], *h_lo[2];
-    float* qkv[2][3];
+    bf16_raw* qkv[2][3];   // Q (bf16, pre-scaled), K (bf16), V (fp16): the attention core's operand formats
     void* wbuf[2] = {nullptr, nullptr};
     for (int s = 0; s < nstream; ++s) {
         wbuf[s] = ws.floats((int64_t)deep_block_packed_bytes(*desc) / 4);
         xn_hi[s] = planes(N * C); xn_lo[s] = planes(N * C);
-        for (int i = 0; i < 3; ++i) qkv[s][i] = ws.floats(N * HD);
+        for (int i = 0; i < 3; ++i) qkv[s][i] = planes(N * HD);
         o_hi[s] = planes(N * HD); o_lo[s] = planes(N * HD);
         h_hi[s] = planes(N * hid); h_lo[s] = planes(N * hid);
     }
@@ -273,17 +274,18 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         const bf16_raw* wl[3] = {wv[s].q_lo, wv[s].k_lo, wv[s].v_lo};
         for (int i = 0; i < 3; ++i) {
             const int src = i == 0 ? s : kvs;
-            gq.p[s * 3 + i] = SpGemmProb{xn_hi[src], xn_lo[src], wh[i], wl[i], lin[i]->bias, nullptr, qkv[s][i], nullptr, nullptr};
+            gq.p[s * 3 + i] = SpGemmProb{xn_hi[src], xn_lo[src], wh[i], wl[i], lin[i]->bias, nullptr, nullptr, qkv[s][i], nullptr};
         }
     }
-    SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_F32, stream));
+    gq.qscale = 1.4426950408889634f / std::sqrt((float)desc->attn.head_dim);   // d^-0.5 (a001:32-34) and exp -> exp2
+    SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_QKV16, stream));
     {
-        const float* qq[2] = {qkv[0][0], qkv[1][0]};
-        const float* kk[2] = {qkv[0][1], qkv[1][1]};
-        const float* vv[2] = {qkv[0][2], qkv[1][2]};
+        const bf16_raw* qq[2] = {qkv[0][0], qkv[1][0]};
+        const bf16_raw* kk[2] = {qkv[0][1], qkv[1][1]};
+        const bf16_raw* vv[2] = {qkv[0][2], qkv[1][2]};
         const float* tt[2] = {pp[0]->attn.bias_table, nstream == 2 ? pp[1]->attn.bias_table : nullptr};
-        SWF_TRY(launch_attn_core_mfma(qq, kk, vv, nullptr, tt, nstream, HD, HD, HD, HD, B, H, W, desc->attn.heads, desc->attn.head_dim,
-                                      desc->attn.shift, stream, o_hi, o_lo));
+        SWF_TRY(launch_attn_core_mfma(nullptr, nullptr, nullptr, nullptr, tt, nstream, HD, HD, HD, HD, B, H, W, desc->attn.heads,
+                                      desc->attn.head_dim, desc->attn.shift, stream, o_hi, o_lo, qq, kk, vv));
     }
     SpGemmBatch gp{};
     gp.scratch = sk; gp.scratch_floats = sk_floats;
