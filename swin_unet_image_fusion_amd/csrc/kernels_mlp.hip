@@ -335,7 +335,9 @@ int mlp_fused_splits(int C, int HID) {
         if (v > 0 && (HID / 128) % v == 0) return v;
     }
     const int chunks = HID / 128;
-    if (C <= 256) return 1;   // levels with many tokens per weight byte: no split, no reduce pass (measured at C = 192)
+    // measured at B=16 256x256 (us, kernel + reduce): C=192 hid 768: S=1 33, S=2 23+6, S=3 32+7; C=384 hid 1536: S=2 56, S=4 38+5,
+    // S=6 32+5, S=12 50+8; hid 768: S=2 35+5, S=3 29+5.  More workgroups streaming the same weights contend for L2 delivery.
+    if (C <= 256) return chunks % 2 == 0 ? 2 : 1;
     return chunks % 2 == 0 ? chunks / 2 : chunks;
 }
 
