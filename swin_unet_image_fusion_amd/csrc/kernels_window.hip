@@ -63,6 +63,9 @@ struct Geo {
     static constexpr int NTK = cround(C, 32) / 16;                       // 16-wide tiles spanning the padded row (residual registers per lane = 4 * NTK)
     static_assert(C % 8 == 0, "8 heads of C/8 channels");
     static constexpr int KC = cround(C, 32), KH = cround(HID, 32);      // K extents padded to the MFMA k-step
+    // row stride (bf16) of the packed fc2 weights: an odd multiple of 16 B, so the 16-row fragment reads from LDS (C = 24) are
+    // conflict-free (the 192-byte rows of KH = 96 were 4-way conflicted: rows r and r+4 on the same banks)
+    static constexpr int LDW2 = KH + 8;
     static constexpr int LDC = KC + 8;                                  // row stride (bf16) of the token-major images: odd multiple of 16 B -> conflict-free b128 reads
     static constexpr int NTC = cceil(C, 16), NTH = cceil(HID, 16);      // 16-wide output tiles
     static constexpr int NH = NTH * 16;
@@ -74,8 +77,8 @@ struct Geo {
     static constexpr size_t p_wqkv_hi = 0, p_wqkv_lo = p_wqkv_hi + size_t(3) * C * KC * 2;     // [3C][KC] bf16 (Wq pre-scaled)
     static constexpr size_t p_wp_hi = p_wqkv_lo + size_t(3) * C * KC * 2, p_wp_lo = p_wp_hi + size_t(C) * KC * 2;
     static constexpr size_t p_w1_hi = p_wp_lo + size_t(C) * KC * 2, p_w1_lo = p_w1_hi + size_t(HID) * KC * 2;
-    static constexpr size_t p_w2_hi = p_w1_lo + size_t(HID) * KC * 2, p_w2_lo = p_w2_hi + size_t(C) * KH * 2;
-    static constexpr size_t p_vec = (p_w2_lo + size_t(C) * KH * 2 + 15) / 16 * 16;             // fp32 vectors
+    static constexpr size_t p_w2_hi = p_w1_lo + size_t(HID) * KC * 2, p_w2_lo = p_w2_hi + size_t(C) * LDW2 * 2;
+    static constexpr size_t p_vec = (p_w2_lo + size_t(C) * LDW2 * 2 + 15) / 16 * 16;           // fp32 vectors
     static constexpr int v_ln1g = 0, v_ln1b = KC, v_ln2g = 2 * KC, v_ln2b = 3 * KC, v_bqkv = 4 * KC, v_bp = v_bqkv + 3 * C, v_b2 = v_bp + C,
                          v_b1 = v_b2 + C, v_end = v_b1 + KH;
     static constexpr size_t wsec = (p_vec + size_t(v_end) * 4 + 15) / 16 * 16;
@@ -524,7 +527,7 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             if constexpr (ROT) {
 #pragma unroll
                 for (int nt = 0; nt < G::NTC; ++nt)
-                    load_frag<1, G::KH>(w2r[nt], wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
+                    load_frag<1, G::LDW2>(w2r[nt], wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
             }
         };
         if constexpr (ROT) {
@@ -596,7 +599,7 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
 #pragma unroll
                 for (int nt = 0; nt < G::NTC; ++nt) {
                     Frag<1> w2;
-                    load_frag<1, G::KH>(w2, wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
+                    load_frag<1, G::LDW2>(w2, wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
 #pragma unroll
                     for (int tt = 0; tt < TT; ++tt) out[tt][nt] = mma_bf16x3<1>(w2, hfrag[tt], out[tt][nt]);
                     if ((nt & 1) == 1) SWF_LOAD_FENCE(G);
@@ -1191,8 +1194,8 @@ __global__ __launch_bounds__(256) void pack_block_kernel(PackArgs a) {
         const int n = i / G::KC, k = i % G::KC;
         put(G::p_w1_hi, G::p_w1_lo, i, k < C ? p.fc1.weight[n * C + k] : 0.f);
     }
-    for (int i = gtid; i < C * G::KH; i += gsz) {
-        const int n = i / G::KH, k = i % G::KH;
+    for (int i = gtid; i < C * G::LDW2; i += gsz) {
+        const int n = i / G::LDW2, k = i % G::LDW2;
         put(G::p_w2_hi, G::p_w2_lo, i, k < HID ? p.fc2.weight[n * HID + k] : 0.f);
     }
     // relative-position bias (a001:113-144) with the shift mask (a001:217-315) folded in, four variants:
