@@ -315,6 +315,29 @@ def test_ragged_640x512_vs_oracle(precision):
         _close(out, ref, TOL_FAST_L2, TOL_FAST_MAX)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+def test_nonsquare_batch3_vs_oracle(precision):
+    """B=3 384x256 pairs, stress weights: odd batch, non-square maps (192x128 ... 12x8 -> the deepest level needs window
+    padding), every fast-tier kernel family at shapes that differ from the benchmark's (window counts that do not divide the
+    CU count, 64-token tile tails in the deep-level GEMMs / MLP kernel)."""
+    cfg = CONFIGS["win8"]
+    m = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(m, seed=3, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ir, vis = (torch.from_numpy(a) for a in synthetic_pair(3, 256, 384, seed_ir=11, seed_vis=12))
+    ref = O.model_forward(sd, cfg, ir, vis)
+    m.to(DEV)
+    m.precision = precision
+    out = m(ir.to(DEV), vis.to(DEV))
+    if precision == "fp32":
+        _close(out, ref, 5e-5)
+    else:
+        _close(out, ref, TOL_FAST_L2, TOL_FAST_MAX)
+    # shards of the batch reproduce the rows of the full batch bit for bit (the multi-GPU contract)
+    part = m(ir[1:].to(DEV), vis[1:].to(DEV))
+    assert torch.equal(part, out[1:])
+
+
 @pytest.mark.parametrize("case", [(24, 3, 96, (1, 32, 48), True, True), (48, 6, 192, (2, 16, 32), True, False),
                                   (96, 12, 384, (1, 16, 16), True, True), (384, 48, 1536, (1, 16, 16), False, True)],
                          ids=["C24", "C48", "C96_onewin", "C384_onewin"])
