@@ -319,7 +319,8 @@ int launch_gemm_sp(const SpGemmBatch& batch, int nprob, int M, int N, int K, int
     if (count(128, 128) >= fill && N % 128 == 0) cfg = 0;
     else if (count(128, 64) >= fill) cfg = 1;
     else cfg = 2;
-    if (const char* e = std::getenv("SWF_SP_CFG")) cfg = e[0] - '0';   // tools/gemm_bench.hip: force a tile shape
+    static const int forced_cfg = [] { const char* e = std::getenv("SWF_SP_CFG"); return e ? e[0] - '0' : -1; }();   // tools/gemm_bench.hip
+    if (forced_cfg >= 0 && forced_cfg <= 2) cfg = forced_cfg;
     if (cfg == 0) {
         dim3 grid(cdiv(M, 128), cdiv(N, 128), nprob * splitk);
         SWF_TRY((launch_sp_cfg<2, 2>(grid, stream, dev, M, N, K, ldo, epi, splitk, kchunk)));

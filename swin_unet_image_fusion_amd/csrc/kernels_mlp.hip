@@ -330,10 +330,8 @@ bool mlp_fused_supported(int C, int HID) {
 
 // hidden splits as a function of the layer shape alone: about two 128-wide chunks per workgroup
 int mlp_fused_splits(int C, int HID) {
-    if (const char* e = std::getenv("SWF_MLP_SPLITS")) {   // tools: tuning override (must divide HID / 128)
-        const int v = atoi(e);
-        if (v > 0 && (HID / 128) % v == 0) return v;
-    }
+    static const int forced = [] { const char* e = std::getenv("SWF_MLP_SPLITS"); return e ? atoi(e) : 0; }();   // tools: tuning override
+    if (forced > 0 && (HID / 128) % forced == 0) return forced;
     const int chunks = HID / 128;
     // measured at B=16 256x256 (us, kernel + reduce): C=192 hid 768: S=1 33, S=2 23+6, S=3 32+7; C=384 hid 1536: S=2 56, S=4 38+5,
     // S=6 32+5, S=12 50+8; hid 768: S=2 35+5, S=3 29+5.  More workgroups streaming the same weights contend for L2 delivery.

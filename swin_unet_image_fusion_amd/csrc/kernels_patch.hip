@@ -34,7 +34,6 @@ struct PatchArgs {
     int Ho, Wo;              // encoder: window-padded merged map; decoder: output extent Hout x Wout
     int K, N, Cout;
     int M;                   // tokens per stream
-    int abl;                 // tools only (SWF_PATCH_ABL): 1 skip the output stores, 2 skip the gather
     int svec;                // outputs (and the skip tensor) allow 16-byte accesses: 4 consecutive channels stay inside one pixel
 };
 
@@ -135,7 +134,7 @@ __global__ __launch_bounds__(256) void patch_fused_kernel(PatchArgs a) {
                     rl[kk] = (bf16)(v - (float)h);
                 }
             };
-            if (t < a.M && a.abl != 2) {
+            if (t < a.M) {
                 if constexpr (DEC) {
                     const int mx = t % a.Wm, t2 = t / a.Wm, my = t2 % a.Hm, b = t2 / a.Hm;
                     const int64_t base = (((int64_t)b * a.H + my) * a.W + mx) * a.Cin;
@@ -197,7 +196,7 @@ __global__ __launch_bounds__(256) void patch_fused_kernel(PatchArgs a) {
         const float rstd = 1.0f / sqrtf(var / (float)N + 1e-5f);
 
         const int t = tile * 64 + wave * 16 + r16;
-        if (t < a.M && !(a.abl == 1 && mean != 123456.f)) {
+        if (t < a.M) {
             if constexpr (DEC) {
                 const int mx = t % a.Wm, t2 = t / a.Wm, my = t2 % a.Hm, b = t2 / a.Hm;
                 const float* skip = a.skip[s];
@@ -320,8 +319,6 @@ int launch_patch_fused(const PatchFusedDesc& d, int nstream, hipStream_t stream)
     }
     a.B = d.B; a.H = d.H; a.W = d.W; a.Cin = d.Cin; a.mh = d.mh; a.mw = d.mw; a.Hm = d.Hm; a.Wm = d.Wm; a.Ho = d.Ho; a.Wo = d.Wo;
     a.K = d.K; a.N = d.N; a.Cout = d.Cout; a.M = (int)d.M;
-    static const int abl = std::getenv("SWF_PATCH_ABL") ? atoi(std::getenv("SWF_PATCH_ABL")) : 0;
-    a.abl = abl;
     // 16-byte gathers need runs of 4 channels inside one pixel (Cin % 4 == 0); 16-byte stores need 4 consecutive output
     // channels inside one pixel / row (decoder: Cout % 4 == 0, encoder: N % 4 == 0)
     const bool gvec = bits % 16 == 0 && d.Cin % 4 == 0;
