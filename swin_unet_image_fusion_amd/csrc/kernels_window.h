@@ -34,8 +34,8 @@ int launch_attn_core_mfma(const float* const* Q, const float* const* K, const fl
 // O_hi / O_lo non-null (head_dim % 4 == 0): the output is written as split-bf16 planes hi = bf16(o), lo = bf16(o - hi)
 // with row stride ldo instead of fp32 O (input format of the deep-level projection GEMM, kernels_deep.h).
 
-// MFMA attention core for 16x16 windows (256 tokens): online softmax over key tiles.  Needs
-// attn_core_mfma16_scratch_floats(nprob) floats of scratch for the per-launch bias (+mask) matrices.
+// MFMA attention core for 16x16 windows (256 tokens): online softmax over key tiles.  bias_scratch is unused
+// (attn_core_mfma16_scratch_floats returns 0; kept for source compatibility of the callers).
 bool attn_core_mfma16_supported(int wh, int ww, int head_dim);
 size_t attn_core_mfma16_scratch_floats(int nprob);
 int launch_attn_core_mfma16(const float* const* Q, const float* const* K, const float* const* V, float* const* O,

@@ -911,28 +911,12 @@ static int launch_attn_mfma_t(const AttnMfmaArgs& a, int nprob, hipStream_t stre
 // stream), 8 waves = the 8 blocks of 32 queries.  A 256x256 fp32 score tile per head would be 256 KB — more than
 // the CU's LDS — so each wave walks the 8 key tiles of 32 keys with an online softmax: running max m, the output
 // accumulator rescaled by exp2(m_old - m_new) per tile, and the denominator carried by the all-ones row of V^T so it
-// is rescaled together with the numerator.  The relative-position bias (+ shift mask) for the whole window is
-// precomputed per launch into a [4 variants][256 keys][256 queries] matrix in global memory (L2-resident, 1 MB per
-// stream) and loaded as the C operand of each tile's first MFMA.
+// is rescaled together with the numerator.  The relative-position bias comes from the 31x31 table staged in LDS and the
+// shift mask from index arithmetic; both form the C operand of each tile's first MFMA.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void bias16_build_kernel(const float* __restrict__ t0, const float* __restrict__ t1,
-                                                           float* __restrict__ dst, int nprob) {
-    constexpr int WH = 16, WW = 16, T = 256, TW = 2 * WW - 1;
-    const int64_t total = (int64_t)nprob * 4 * T * T;
-    for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (int64_t)gridDim.x * blockDim.x) {
-        const int q = (int)(e % T), key = (int)((e / T) % T), variant = (int)((e / (T * T)) % 4), p = (int)(e / (4 * T * T));
-        const int ky = key / WW, kx = key % WW, qy = q / WW, qx = q % WW;
-        float v = (p ? t1 : t0)[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
-        const bool my = (variant & 2) && ((ky >= WH - WH / 2) != (qy >= WH - WH / 2));
-        const bool mx = (variant & 1) && ((kx >= WW - WW / 2) != (qx >= WW - WW / 2));
-        if (my || mx) v = -1e10f;   // scores[mask] = -1e10 (a001:310)
-        dst[e] = v * kLog2e;
-    }
-}
-
 struct Attn16Args {
     const float* Q[2]; const float* K[2]; const float* V[2]; float* O[2];
-    const float* bias_full;   // [nprob][4][256][256]
+    const float* table[2];    // relative-position bias table [(2*16-1)^2] per stream
     int ldq, ldk, ldv, ldo, B, H, W, heads, shift;
 };
 
@@ -945,6 +929,8 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     bf16* qimg = reinterpret_cast<bf16*>(sm16);                    // [256][QS]
     bf16* kimg = qimg + T * QS;
     f16* vt = reinterpret_cast<f16*>(kimg + T * QS);               // [D + 1][VRS]; row D = 1.0
+    constexpr int TW = 2 * WW - 1, NTAB = (2 * WH - 1) * TW;
+    float* tab = reinterpret_cast<float*>(sm16 + (size_t(2) * T * QS * 2 + size_t(D + 1) * VRS * 2 + 15) / 16 * 16);   // [31][31], exp2 units
 
     const int p = blockIdx.z, head = blockIdx.y, tid = threadIdx.x, lane = tid & 63, qb = tid >> 6;
     const int H = a.H, W = a.W, nwx = W / WW, nwy = H / WH;
@@ -954,6 +940,7 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     const float qscale = kLog2e / sqrtf((float)D);
 
     for (int i = tid; i < VRS; i += 512) vt[D * VRS + i] = (f16)1.0f;
+    for (int i = tid; i < NTAB; i += 512) tab[i] = a.table[p][i] * kLog2e;
     if constexpr (QS != D) {
         for (int i = tid; i < T * (QS - D); i += 512) {
             const int tok = i / (QS - D), c = D + i % (QS - D);
@@ -996,8 +983,14 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     const int r = lane & 31, hf = lane >> 5;
     const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int q = 32 * qb + r;
-    const int variant = a.shift ? ((wy == nwy - 1) * 2 + (wx == nwx - 1)) : 0;
-    const float* bias = a.bias_full + ((int64_t)(p * 4 + variant) * T) * T + q;
+    // relative-position bias (a001:113-144) from the 31x31 table in LDS, shift mask (a001:217-315) by index arithmetic: only
+    // windows in the last window row / column of a shifted block hold two region labels, split at wh/2 (ww/2).  (A
+    // precomputed [4][256][256] matrix per stream cost 256 KB of L2 reads per (window, head): 34 GB per launch at 1024^2.)
+    const int qy = q / WW, qx = q % WW;
+    const bool vrow = a.shift && wy == nwy - 1, vcol = a.shift && wx == nwx - 1;
+    const bool colmask0 = vcol && (qx >= WW - WW / 2), colmask1 = vcol && !(qx >= WW - WW / 2);   // key column half 0 / 1 masked for this query
+    const float* tq = tab + (WH - 1 - qy) * TW + (WW - 1 - qx) + 4 * hf;
+    constexpr float NEG = -1e10f * kLog2e;
     bf16x8 qf[QKS];
 #pragma unroll
     for (int ks = 0; ks < QKS; ++ks)
@@ -1011,7 +1004,12 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     for (int kt = 0; kt < T / 32; ++kt) {
         f32x16 acc;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = bias[(int64_t)(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hf) * T];
+        for (int i = 0; i < 16; ++i) {
+            // register i of key tile kt is key row ky = 2kt + (i >> 3), column kx = 8((i >> 2) & 1) + 4hf + (i & 3)
+            const float bv = tq[(2 * kt + (i >> 3)) * TW + 8 * ((i >> 2) & 1) + (i & 3)];
+            const bool rowmask = vrow && ((2 * kt + (i >> 3) >= WH - WH / 2) != (qy >= WH - WH / 2));
+            acc[i] = (rowmask || (((i >> 2) & 1) ? colmask1 : colmask0)) ? NEG : bv;
+        }
         const bf16* krow = kimg + (32 * kt + r) * QS;
 #pragma unroll
         for (int ks = 0; ks < QKS; ++ks) {
@@ -1070,7 +1068,7 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
 template <int D>
 static int launch_attn16_t(const Attn16Args& a, int nprob, hipStream_t stream) {
     constexpr int QS = cround(D, 8);
-    constexpr size_t lds = size_t(2) * 256 * QS * 2 + size_t(D + 1) * (256 + 8) * 2;
+    constexpr size_t lds = (size_t(2) * 256 * QS * 2 + size_t(D + 1) * (256 + 8) * 2 + 15) / 16 * 16 + size_t(31) * 31 * 4;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     if (lds > 64 * 1024)
@@ -1084,17 +1082,14 @@ static int launch_attn16_t(const Attn16Args& a, int nprob, hipStream_t stream) {
     return check_launch("attn_core_mfma16");
 }
 
-size_t attn_core_mfma16_scratch_floats(int nprob) { return (size_t)nprob * 4 * 256 * 256; }
+size_t attn_core_mfma16_scratch_floats(int nprob) { (void)nprob; return 0; }
 
 int launch_attn_core_mfma16(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
                             const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
                             int heads, int head_dim, int shift, float* bias_scratch, hipStream_t stream) {
-    if (!bias_scratch) return fail(SWF_ERR_WORKSPACE, "attn_core_mfma16: no bias scratch");
-    hipLaunchKernelGGL(bias16_build_kernel, dim3(512), dim3(256), 0, stream, table[0], nprob > 1 ? table[1] : table[0], bias_scratch, nprob);
-    SWF_TRY(check_launch("bias16_build"));
+    (void)bias_scratch;   // no longer used: the bias comes from the 31x31 table staged in LDS
     Attn16Args a{};
-    for (int i = 0; i < nprob; ++i) { a.Q[i] = Q[i]; a.K[i] = K[i]; a.V[i] = V[i]; a.O[i] = O[i]; }
-    a.bias_full = bias_scratch;
+    for (int i = 0; i < nprob; ++i) { a.Q[i] = Q[i]; a.K[i] = K[i]; a.V[i] = V[i]; a.O[i] = O[i]; a.table[i] = table[i]; }
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.W = W; a.heads = heads; a.shift = shift;
     switch (head_dim) {
         case 3: return launch_attn16_t<3>(a, nprob, stream);
