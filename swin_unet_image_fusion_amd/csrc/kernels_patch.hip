@@ -154,6 +154,29 @@ __global__ __launch_bounds__(256) void patch_fused_kernel(PatchArgs a) {
                 }
             }
         }
+        // decoder: the U-Net skip values this lane will add (addresses depend on the token only) are requested now, so their
+        // HBM round trip overlaps the conv and the LayerNorm instead of serialising the scatter
+        float4 skv[DEC ? NT : 1];
+        if constexpr (DEC) {
+            const int tq = tile * 64 + wave * 16 + r16;
+            if (a.svec && a.skip[s] && tq < a.M) {
+                const int mx = tq % a.Wm, t2 = tq / a.Wm, my = t2 % a.Hm, b = t2 / a.Hm;
+                int pq = (4 * g) / a.Cout, c = (4 * g) % a.Cout;
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    skv[nt] = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (nt * 16 + 4 * g < N) {
+                        int ph = 0, pw = pq;
+                        while (pw >= a.mw) { pw -= a.mw; ++ph; }
+                        const int y = my * a.mh + ph, xx = mx * a.mw + pw;
+                        if (y < a.Ho && xx < a.Wo)
+                            skv[nt] = *reinterpret_cast<const float4*>(a.skip[s] + (((int64_t)b * a.Ho + y) * a.Wo + xx) * a.Cout + c);
+                    }
+                    c += 16;
+                    while (c >= a.Cout) { c -= a.Cout; ++pq; }
+                }
+            }
+        }
         __syncthreads();
 
         // ---- Z^T tiles: D[channel 4g+j][token r16] = W . A^T, bf16x3 ----
@@ -217,10 +240,7 @@ __global__ __launch_bounds__(256) void patch_fused_kernel(PatchArgs a) {
                             if (y < a.Ho && xx < a.Wo) {
                                 const int64_t o = (((int64_t)b * a.Ho + y) * a.Wo + xx) * a.Cout + c;
                                 float4 q = make_float4(v[0], v[1], v[2], v[3]);
-                                if (skip) {
-                                    const float4 k4 = *reinterpret_cast<const float4*>(skip + o);
-                                    q.x += k4.x; q.y += k4.y; q.z += k4.z; q.w += k4.w;
-                                }
+                                if (skip) { q.x += skv[nt].x; q.y += skv[nt].y; q.z += skv[nt].z; q.w += skv[nt].w; }
                                 *reinterpret_cast<float4*>(a.out[s] + o) = q;
                             }
                         } else {
