@@ -22,6 +22,13 @@
 #include <mutex>
 #include <cstdlib>
 
+#ifdef SWF_MLP_PROBE   // tools/mlp_probe.hip: wall-clock stamps of workgroup (0,0,0) wave 0 at the phase boundaries
+__device__ unsigned long long swf_mlp_probe[64];
+#define SWF_PROBE(i) do { if (blockIdx.x == SWF_MLP_PROBE && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) swf_mlp_probe[i] = wall_clock64(); } while (0)
+#else
+#define SWF_PROBE(i) do { } while (0)
+#endif
+
 namespace swf {
 
 namespace {
@@ -101,23 +108,30 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         }
     };
 
+    SWF_PROBE(0);
     const int hb0 = split * a.nchunks * 128;
-#pragma unroll
-    for (int f = 0; f < D; ++f) frag_load(f, hb0);   // in flight during the LayerNorm prologue
-
-    // ---- LN2 of the 64 token rows -> split-bf16 image (4 threads per row) ----
+    // ---- LN2 of the 64 token rows -> split-bf16 image (4 threads per row).  Vector memory returns in order, so the token
+    //      rows (and gamma / beta, which travel through the idle H buffer) are requested BEFORE the weight ring's first D
+    //      fragments: the ring then fills during the LayerNorm arithmetic instead of delaying it (3.1 -> 1.x us at C=192). ----
     {
         const int row = tid >> 2, sub = tid & 3;
         const int m = min(tile * 64 + row, a.M - 1);   // rows past M are computed on a clamped copy and never stored
         const float* xr = a.x[s] + (int64_t)m * C;
         constexpr int NV = C / 16;
         float4 v[NV];
+#pragma unroll
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + 16 * i + 4 * sub);
+        float* gb = reinterpret_cast<float*>(h_hi);   // [2][C] fp32: gamma, beta
+        float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (tid < C / 2) gbv = *reinterpret_cast<const float4*>((tid < C / 4 ? a.gamma[s] : a.beta[s] - C) + 4 * tid);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int f = 0; f < D; ++f) frag_load(f, hb0);   // the ring's first fragments: in flight during the LayerNorm arithmetic
+        __builtin_amdgcn_sched_barrier(0);
+        if (tid < C / 2) *reinterpret_cast<float4*>(gb + 4 * tid) = gbv;
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            v[i] = *reinterpret_cast<const float4*>(xr + 16 * i + 4 * sub);
-            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        }
+        for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         sum += __shfl_xor(sum, 1);
         sum += __shfl_xor(sum, 2);
         const float mean = sum * (1.0f / C);
@@ -130,10 +144,11 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         var += __shfl_xor(var, 1);
         var += __shfl_xor(var, 2);
         const float rstd = 1.0f / sqrtf(var * (1.0f / C) + 1e-5f);
+        __syncthreads();   // gamma / beta are in LDS
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int c = 16 * i + 4 * sub;
-            const float4 gm = *reinterpret_cast<const float4*>(a.gamma[s] + c), bt = *reinterpret_cast<const float4*>(a.beta[s] + c);
+            const float4 gm = *reinterpret_cast<const float4*>(gb + c), bt = *reinterpret_cast<const float4*>(gb + C + c);
             const float n[4] = {(v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y,
                                 (v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w};
             bf16x4 h, l;
@@ -144,6 +159,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         }
     }
     __syncthreads();
+    SWF_PROBE(1);
 
     f32x16 acc2[2 * NF + NH];
 #pragma unroll
@@ -190,6 +206,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
             mma3(acc1[1], wh, wl, ch1, cl1);
             __builtin_amdgcn_sched_barrier(0);
         }
+        SWF_PROBE(2 + 4 * (ch & 7));
         // bias, ELU, split: register 4g+j of token half t is hidden 32w + 8g + 4hf + j of token 32t + r
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -205,7 +222,9 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
                 *reinterpret_cast<bf16x4*>(h_hi + (32 * t + r) * LDH + hl) = h;
                 *reinterpret_cast<bf16x4*>(h_lo + (32 * t + r) * LDH + hl) = l;
             }
+        SWF_PROBE(3 + 4 * (ch & 7));
         __syncthreads();   // the whole H chunk is in place
+        SWF_PROBE(4 + 4 * (ch & 7));
         // ---- fc2: out^T tiles of this wave += W2[:, chunk] . H^T ----
         bf16x8 xh, xl;   // the half tile's token half
         {
@@ -253,31 +272,45 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
             }
             __builtin_amdgcn_sched_barrier(0);
         }
+        SWF_PROBE(5 + 4 * (ch & 7));
         __syncthreads();   // H is free for the next chunk
     }
 
-    // ---- epilogue: register 4g+j of (tile nt, token half t) is channel 32nt + 8g + 4hf + j of token 32t + r ----
-    float* part = a.splits > 1 ? a.scratch + ((int64_t)(s * a.splits + split) * a.M) * C : nullptr;
+    SWF_PROBE(40);
+    // ---- epilogue: register 4g+j of (tile nt, token half t) is channel 32nt + 8g + 4hf + j of token 32t + r.  The out tile goes
+    //      through the (now free) A image as fp32 rows and leaves as whole rows: consecutive lanes = consecutive channels
+    //      (per-lane 16-byte stores at a row stride took 3-5 us here). ----
+    constexpr int ORS = C + 4;   // row stride (floats): odd multiple of 16 B
+    static_assert(64 * ORS * 4 <= 2 * 64 * LDA * 2, "out tile must fit the A image");
+    float* otile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < 2 * NF + NH; ++i) {
         const int nt = i < 2 * NF ? wave + 4 * (i >> 1) : half_nt;
         const int t = i < 2 * NF ? (i & 1) : half_tok;
-        const int m = tile * 64 + 32 * t + r;
-        if (m >= a.M) continue;
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            const int c = 32 * nt + 8 * g + 4 * hf;
-            float4 v = make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
-            if (part) {
-                *reinterpret_cast<float4*>(part + (int64_t)m * C + c) = v;
-            } else {
-                const float4 b = *reinterpret_cast<const float4*>(a.b2[s] + c);
-                const float4 x = *reinterpret_cast<const float4*>(a.x[s] + (int64_t)m * C + c);
-                v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
-                *reinterpret_cast<float4*>(a.out[s] + (int64_t)m * C + c) = v;
-            }
+        for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<float4*>(otile + (32 * t + r) * ORS + 32 * nt + 8 * g + 4 * hf) =
+                make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
+    }
+    __syncthreads();
+    float* part = a.splits > 1 ? a.scratch + ((int64_t)(s * a.splits + split) * a.M) * C : nullptr;
+    constexpr int C4 = C / 4;
+#pragma unroll 4
+    for (int idx = tid; idx < 64 * C4; idx += 256) {
+        const int row = idx / C4, c = (idx % C4) * 4;
+        const int m = tile * 64 + row;
+        if (m >= a.M) continue;
+        float4 v = *reinterpret_cast<const float4*>(otile + row * ORS + c);
+        if (part) {
+            *reinterpret_cast<float4*>(part + (int64_t)m * C + c) = v;
+        } else {
+            const float4 b = *reinterpret_cast<const float4*>(a.b2[s] + c);
+            const float4 x = *reinterpret_cast<const float4*>(a.x[s] + (int64_t)m * C + c);
+            v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
+            *reinterpret_cast<float4*>(a.out[s] + (int64_t)m * C + c) = v;
         }
     }
+    SWF_PROBE(41);
 }
 
 // out = x + b2 + sum of the hidden-split partials, fixed order

@@ -1,0 +1,48 @@
+// Phase timeline of one workgroup of the fused MLP kernel (kernels_mlp.hip) at the level-3 / level-4 shapes.
+//   hipcc -O3 -std=c++17 --offload-arch=gfx950 -DSWF_MLP_PROBE=<workgroup x index> tools/mlp_probe.hip \
+//         -Lswin_unet_image_fusion_amd -lswinfuse -Wl,-rpath,'$ORIGIN/../swin_unet_image_fusion_amd' -o tools/mlp_probe
+// wall_clock64() ticks at 100 MHz (10 ns).
+#include "../swin_unet_image_fusion_amd/csrc/kernels_mlp.hip"
+
+#include <cstdio>
+#include <vector>
+
+using namespace swf;
+#define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
+
+int main() {
+    struct Shape { const char* name; int M, C, HID; } shapes[] = {{"L3 enc", 4096, 192, 768}, {"L3 dec", 4096, 192, 384}, {"L4 enc", 1024, 384, 1536}, {"L4 dec", 1024, 384, 768}};
+    hipStream_t st;
+    CK(hipStreamCreate(&st));
+    for (const Shape& sh : shapes) {
+        const size_t xe = (size_t)sh.M * sh.C, we = (size_t)sh.HID * sh.C;
+        float *x[2], *out[2], *g, *b, *b1, *b2, *scratch;
+        bf16_raw* w[4];
+        for (int s = 0; s < 2; ++s) { CK(hipMalloc(&x[s], xe * 4)); CK(hipMalloc(&out[s], xe * 4)); CK(hipMemset(x[s], 0, xe * 4)); }
+        CK(hipMalloc(&g, 4096)); CK(hipMalloc(&b, 4096)); CK(hipMalloc(&b1, 8192)); CK(hipMalloc(&b2, 4096));
+        CK(hipMemset(g, 0, 4096)); CK(hipMemset(b, 0, 4096)); CK(hipMemset(b1, 0, 8192)); CK(hipMemset(b2, 0, 4096));
+        for (int i = 0; i < 4; ++i) { CK(hipMalloc(&w[i], we * 2)); CK(hipMemset(w[i], 0, we * 2)); }
+        const int S = mlp_fused_splits(sh.C, sh.HID);
+        CK(hipMalloc(&scratch, xe * 4 * 2 * S));
+        MlpFusedDesc d{};
+        for (int s = 0; s < 2; ++s) {
+            d.x[s] = x[s]; d.out[s] = out[s]; d.gamma[s] = g; d.beta[s] = b; d.w1_hi[s] = w[0]; d.w1_lo[s] = w[1]; d.w2_hi[s] = w[2]; d.w2_lo[s] = w[3];
+            d.b1[s] = b1; d.b2[s] = b2;
+        }
+        d.scratch = scratch; d.scratch_floats = (int64_t)xe * 2 * S; d.M = sh.M; d.C = sh.C; d.HID = sh.HID;
+        for (int it = 0; it < 3; ++it)
+            if (launch_mlp_fused(d, 2, st) != SWF_OK) { printf("launch failed: %s\n", swf_last_error_string()); return 1; }
+        CK(hipStreamSynchronize(st));
+        unsigned long long h[64];
+        CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(swf_mlp_probe), sizeof(h)));
+        const int nch = sh.HID / 128 / S;
+        printf("%s C=%d hid=%d S=%d chunks/WG=%d (us from kernel entry of WG %d): LN done %.2f", sh.name, sh.C, sh.HID, S, nch, SWF_MLP_PROBE, (h[1] - h[0]) * 0.01);
+        for (int c = 0; c < nch && c < 8; ++c)
+            printf(" | ch%d fc1 %.2f H %.2f bar %.2f fc2 %.2f", c, (h[2 + 4 * c] - h[0]) * 0.01, (h[3 + 4 * c] - h[0]) * 0.01, (h[4 + 4 * c] - h[0]) * 0.01, (h[5 + 4 * c] - h[0]) * 0.01);
+        printf(" | loop end %.2f | done %.2f\n", (h[40] - h[0]) * 0.01, (h[41] - h[0]) * 0.01);
+        for (int s = 0; s < 2; ++s) { hipFree(x[s]); hipFree(out[s]); }
+        hipFree(g); hipFree(b); hipFree(b1); hipFree(b2); hipFree(scratch);
+        for (int i = 0; i < 4; ++i) hipFree(w[i]);
+    }
+    return 0;
+}
