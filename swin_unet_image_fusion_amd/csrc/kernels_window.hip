@@ -36,6 +36,13 @@
 #define SWF_C48_TT2 1   // C = 48 block kernel: 32 tokens per wave (see window_block_kernel)
 #endif
 
+#ifdef SWF_WIN_PROBE   // tools/win_probe.hip: wall-clock stamps (10 ns ticks) of workgroup SWF_WIN_PROBE, thread 0, first window
+__device__ unsigned long long swf_win_probe[16];
+#define SWF_WPROBE(i) do { if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0 && win == (int)blockIdx.x) swf_win_probe[i] = wall_clock64(); } while (0)
+#else
+#define SWF_WPROBE(i) do { } while (0)
+#endif
+
 namespace swf {
 
 using bf16 = __bf16;
@@ -110,7 +117,9 @@ struct WinArgs {
     const float* in[2];
     float* out[2];
     const char* packed[2];
+    const char* warm[2];     // packed images of the NEXT block of the stage (or nullptr): touched at the end of this launch
     int B, H, W, shift, cross;
+    int warm_bytes;          // bytes of one packed image to touch
 };
 
 // ------------------------------------------------------------------------------------------
@@ -226,7 +235,7 @@ __device__ __forceinline__ void layernorm_regs(const float4 (&res)[G::NTK], bf16
 // 256 threads, wave w owns tokens [32(w&1), +32) of stream w>>1: every weight fragment a wave pulls from L2 feeds two MFMAs
 // (half the L1->register traffic per token, the measured bound of the L2-sourced variants) and two workgroups share a CU.
 template <int C_, int HID_, int TT>
-__global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void window_block_kernel(WinArgs args) {
+__global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel(WinArgs args) {
     using G = Geo<C_, HID_>;
     constexpr int C = G::C, D = G::D, T = G::T, LDC = G::LDC, KS = G::KC / 32;
     constexpr int NTHR = 512 / TT;              // threads per workgroup
@@ -243,6 +252,9 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
     uint4* maskt = reinterpret_cast<uint4*>(smem + G::l_mask);
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+#ifdef SWF_WIN_PROBE
+    if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0) swf_win_probe[10] = wall_clock64();
+#endif
     const int H = args.H, W = args.W;
     const int nwx = W / G::WW, nwy = H / G::WH;
     const int nwin = args.B * nwx * nwy;
@@ -327,11 +339,16 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             for (int nt = 0; nt < NTK; ++nt) res[tt][nt] = pre[tt][nt];
         if (win + (int)gridDim.x < nwin) SWF_PREFETCH(win + gridDim.x);
 
+        SWF_WPROBE(0);
+#ifdef SWF_WIN_PROBE
+        if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0) swf_win_probe[11] = wall_clock64();
+#endif
         // ---- LN1 -> A image (own rows) ----
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
             layernorm_regs<G>(res[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, wvec(ws), G::v_ln1g, G::v_ln1b, r16, g);
 
+        SWF_WPROBE(1);
         // ---- Q, K, V projections of the own rows.  Q for the own stream; K and V for the stream whose attention
         //      reads these tokens as keys: itself, or the other one in a cross block (a002:67-82) ----
         {
@@ -376,8 +393,10 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
                 SWF_LOAD_FENCE(G);
             }
         }
+        SWF_WPROBE(2);
         __syncthreads();   // all Q / K / V^T rows of the window are in place
 
+        SWF_WPROBE(3);
         // ---- attention.  wave -> (stream, 32-query block, 4 heads) ----
         {
             // TT = 1: wave -> (stream, 32-query block, 4 heads);  TT = 2: wave -> (stream, 32-query block), all 8 heads
@@ -482,8 +501,10 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
                     }
             }
         }
+        SWF_WPROBE(4);
         __syncthreads();   // O rows complete
 
+        SWF_WPROBE(5);
         // ---- output projection + residual (own rows; transposed tiles: a lane holds 4 channels of one token) ----
         {
             Frag<KS> x[TT];
@@ -511,7 +532,7 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
         // registers to spend): the fc1 fragments (+ bias) of chunk hc+1 are requested as soon as chunk hc's fc1 MFMAs have
         // consumed theirs, the fc2 fragments of chunk hc+1 as soon as chunk hc's fc2 MFMAs have; chunk 0's go out here, under
         // LN2.  Scheduling fences pin the issue points (hipcc otherwise sinks the loads next to their uses).
-        constexpr bool ROT = !G::WLDS && TT == 2 && C_ == 96 && SWF_MLP_ROTATE && G::HID % 32 == 0;
+        constexpr bool ROT = !G::WLDS && TT == 2 && SWF_MLP_ROTATE && G::HID % 32 == 0;
         Frag<ROT ? KS : 1> w1a, w1b;
         Frag<1> w2r[ROT ? G::NTC : 1];
         float4 b1a, b1b;
@@ -536,11 +557,13 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             __builtin_amdgcn_sched_barrier(0);
         }
 
+        SWF_WPROBE(6);
         // ---- LN2 -> A image (own rows) ----
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
             layernorm_regs<G>(res[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, wvec(ws), G::v_ln2g, G::v_ln2b, r16, g);
 
+        SWF_WPROBE(7);
         // ---- MLP, own rows, walking the hidden dimension in chunks of 32: fc1 + ELU for the chunk -> split-bf16
         //      image over the wave's own A rows (xn2 already sits in registers) -> one k-step of fc2.  The hidden
         //      activations never exist as a whole. ----
@@ -607,7 +630,6 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             }
             } else {
                 constexpr int NCH = G::KH / 32;
-                static_assert(NCH % 2 == 0, "rotating MLP path is unrolled by two chunks");
 #pragma unroll 2
                 for (int hc = 0; hc < NCH; ++hc) {
                     bf16* hhi = hb_hi[hc & 1];
@@ -661,6 +683,7 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
                 }
         }
 
+        SWF_WPROBE(8);
         // ---- store the own rows (un-shift = same index map as the load) ----
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
@@ -669,8 +692,25 @@ __global__ __launch_bounds__(512 / TT, (TT == 2 && C_ == 96) ? 1 : 2) void windo
             for (int nt = 0; nt < NTK; ++nt)
                 if (nt * 16 + 4 * g < C) *reinterpret_cast<float4*>(dst + nt * 16 + 4 * g) = res[tt][nt];
         }
+        SWF_WPROBE(9);
+#ifdef SWF_WIN_PROBE
+        if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0) swf_win_probe[12] = wall_clock64();
+#endif
     }
 #undef SWF_PREFETCH
+    // ---- L2 warm-up for the next block of the stage.  Its weights were last used a whole forward ago: cold, every fragment
+    //      load of the next launch would go to HBM / MALL (measured at C = 96: 58 us with warm weights, 78 us in the model).
+    //      The L2s are per XCD and blocks are dealt to XCDs round-robin (speed only), so the workgroups of one XCD together
+    //      touch the whole image: workgroup b covers slice b / 8 of gridDim.x / 8 slices.  Issued last: nothing waits on it. ----
+    if (args.warm[0]) {
+        const int nsl = max(1, (int)gridDim.x / 8), sl = ((int)blockIdx.x / 8) % nsl;
+        const int lines = (args.warm_bytes + 127) / 128;                       // 128-byte lines of one image
+        const int per = (lines + nsl - 1) / nsl, l0 = sl * per, l1 = min(lines, l0 + per);
+        unsigned acc = 0;
+        for (int s2 = 0; s2 < 2; ++s2)
+            for (int l = l0 + tid; l < l1; l += NTHR) acc ^= *reinterpret_cast<const unsigned*>(args.warm[s2] + (size_t)l * 128);
+        if (acc == 0x9e3779b9u && args.B < 0) args.out[0][0] = 0.f;   // never true: keeps the loads alive
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1235,7 +1275,7 @@ static int launch_t(const WinArgs& a, int nwin, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::l_total);
     });
     if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window_block): %s", hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((window_block_kernel<C, HID, TT>), dim3(std::min(nwin, TT * num_cus())), dim3(512 / TT), G::l_total, stream, a);
+    hipLaunchKernelGGL((window_block_kernel<C, HID, TT>), dim3(std::min(nwin, num_cus())), dim3(512 / TT), G::l_total, stream, a);
     return check_launch("window_block");
 }
 
@@ -1282,8 +1322,12 @@ int pack_window_block(const swf_block_desc& d, const swf_block_stream_params& px
 }
 
 int launch_window_block(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in,
-                        const float* y_in, float* x_out, float* y_out, int B, int H, int W, hipStream_t stream) {
+                        const float* y_in, float* x_out, float* y_out, int B, int H, int W, hipStream_t stream,
+                        const void* next_packed_x, const void* next_packed_y) {
     WinArgs a;
+    a.warm[0] = static_cast<const char*>(next_packed_x); a.warm[1] = static_cast<const char*>(next_packed_y);
+    if (!a.warm[1]) a.warm[0] = nullptr;
+    a.warm_bytes = (int)window_block_packed_bytes(d);
     a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
     a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;

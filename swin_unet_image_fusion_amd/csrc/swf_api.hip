@@ -341,10 +341,11 @@ static int check_block(const swf_block_desc* desc, const swf_block_stream_params
 static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_params* px,
                             const swf_block_stream_params* py, const float* x_in, const float* y_in, float* x_out,
                             float* y_out, int B, int H, int W, void* workspace, size_t workspace_bytes,
-                            hipStream_t stream, const void* prepacked_x = nullptr, const void* prepacked_y = nullptr) {
+                            hipStream_t stream, const void* prepacked_x = nullptr, const void* prepacked_y = nullptr,
+                            const void* next_x = nullptr, const void* next_y = nullptr) {
     if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W)) {
         if (prepacked_x && prepacked_y)   // model path: weights were packed once (swf_model_pack_weights)
-            return launch_window_block(*desc, prepacked_x, prepacked_y, x_in, y_in, x_out, y_out, B, H, W, stream);
+            return launch_window_block(*desc, prepacked_x, prepacked_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_x, next_y);
         // block-level entry: pack this block's weights into the workspace, then one fused launch
         const size_t pb = window_block_packed_bytes(*desc);
         if (!workspace || workspace_bytes < 2 * pb) return fail(SWF_ERR_WORKSPACE, "fused block workspace too small (need %zu B)", 2 * pb);
@@ -670,7 +671,10 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
         d.attn.shift = i & 1;      // normal window, then shifted window (a009:102-105)
         const void* pkx = (packed && pb) ? packed + (size_t)(2 * i) * pb : nullptr;
         const void* pky = (packed && pb) ? packed + (size_t)(2 * i + 1) * pb : nullptr;
-        SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream, pkx, pky));
+        const void* nkx = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 2) * pb : nullptr;   // next block of the stage: warmed in L2
+        const void* nky = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 3) * pb : nullptr;
+        SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream, pkx, pky,
+                                 nkx, nky));
         xi = x_out; yi = y_out;
     }
     return SWF_OK;
