@@ -18,9 +18,13 @@ int pack_window_block(const swf_block_desc& d, const swf_block_stream_params& px
 
 int launch_window_block(const swf_block_desc& d, const void* packed_x, const void* packed_y,
                         const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
-                        hipStream_t stream, const void* next_packed_x = nullptr, const void* next_packed_y = nullptr);
+                        hipStream_t stream, const void* next_packed_x = nullptr, const void* next_packed_y = nullptr,
+                        size_t next_bytes = 0);
 // next_packed_*: packed images of the block that runs next with different weights (or nullptr): this launch ends by touching
-// them so that they are L2-resident when that block starts.
+// them (next_bytes each; 0 = the size of this block's own image) so that they are L2-resident when that block starts.
+
+// Touch a buffer from every XCD so that it is L2-resident for the next launch (a fused stage that follows a deep-level stage).
+int launch_l2_warm(const void* p, size_t bytes, hipStream_t stream);
 
 // MFMA attention core on projection buffers (8x8 windows, head_dim in {3,6,12,24,48}); same contract as
 // launch_attn_core of the exact tier, fast-tier arithmetic (bf16 QK^T, fp16 PV, fp32 softmax).

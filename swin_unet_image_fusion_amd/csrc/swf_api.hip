@@ -342,10 +342,10 @@ static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_p
                             const swf_block_stream_params* py, const float* x_in, const float* y_in, float* x_out,
                             float* y_out, int B, int H, int W, void* workspace, size_t workspace_bytes,
                             hipStream_t stream, const void* prepacked_x = nullptr, const void* prepacked_y = nullptr,
-                            const void* next_x = nullptr, const void* next_y = nullptr) {
+                            const void* next_x = nullptr, const void* next_y = nullptr, size_t next_bytes = 0) {
     if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W)) {
         if (prepacked_x && prepacked_y)   // model path: weights were packed once (swf_model_pack_weights)
-            return launch_window_block(*desc, prepacked_x, prepacked_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_x, next_y);
+            return launch_window_block(*desc, prepacked_x, prepacked_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_x, next_y, next_bytes);
         // block-level entry: pack this block's weights into the workspace, then one fused launch
         const size_t pb = window_block_packed_bytes(*desc);
         if (!workspace || workspace_bytes < 2 * pb) return fail(SWF_ERR_WORKSPACE, "fused block workspace too small (need %zu B)", 2 * pb);
@@ -661,7 +661,10 @@ static swf_block_desc level_block_desc(const swf_model_desc* d, int lvl, bool en
 // stride of window_block_packed_bytes(desc)
 static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                             const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
-                            void* workspace, size_t workspace_bytes, hipStream_t stream, const char* packed = nullptr) {
+                            void* workspace, size_t workspace_bytes, hipStream_t stream, const char* packed = nullptr,
+                            const char* after = nullptr, size_t after_pb = 0) {
+    // `after`: packed images (x, then y at + after_pb) of the first block of the NEXT stage when that is a fused-kernel stage
+    // too: the last block of this stage warms them
     const float* xi = x_in;
     const float* yi = y_in;
     const size_t pb = packed ? block_packed_bytes(*desc) : 0;
@@ -671,10 +674,10 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
         d.attn.shift = i & 1;      // normal window, then shifted window (a009:102-105)
         const void* pkx = (packed && pb) ? packed + (size_t)(2 * i) * pb : nullptr;
         const void* pky = (packed && pb) ? packed + (size_t)(2 * i + 1) * pb : nullptr;
-        const void* nkx = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 2) * pb : nullptr;   // next block of the stage: warmed in L2
-        const void* nky = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 3) * pb : nullptr;
+        const void* nkx = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 2) * pb : (i == 3 ? after : nullptr);   // next block: warmed in L2
+        const void* nky = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 3) * pb : (i == 3 && after ? after + after_pb : nullptr);
         SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream, pkx, pky,
-                                 nkx, nky));
+                                 nkx, nky, i == 3 ? after_pb : 0));
         xi = x_out; yi = y_out;
     }
     return SWF_OK;
@@ -1023,8 +1026,15 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
         swf_block_stream_params px[4], py[4];
         for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->enc_blk[s][i][0]); py[i] = make_stream_params(arena, L->enc_blk[s][i][1]); }
         swf_block_desc bd = level_block_desc(desc, s, true);
+        // the first block of the next fused-kernel stage is warmed by this stage's last block
+        const char* after = nullptr;
+        size_t after_pb = 0;
+        if (packed && s + 1 < n) {
+            swf_block_desc nb = level_block_desc(desc, s + 1, true);
+            if (window_block_packed_bytes(nb) && plan.enc_on[s + 1]) { after = packed + plan.enc[s + 1]; after_pb = window_block_packed_bytes(nb); }
+        }
         SWF_TRY(block_pair4_impl(&bd, px, py, act[s][0], act[s][1], act[s][0], act[s][1], B, ls[s].Ho, ls[s].Wo, scratch, scratch_bytes, stream,
-                                 (packed && plan.enc_on[s]) ? packed + plan.enc[s] : nullptr));
+                                 (packed && plan.enc_on[s]) ? packed + plan.enc[s] : nullptr, after, after_pb));
         cur[0] = act[s][0]; cur[1] = act[s][1];
     }
     // decoder (a013:221-227): the skip add of stage j+1 is folded into stage j's unmerge epilogue,
@@ -1034,8 +1044,16 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
         swf_block_stream_params px[4], py[4];
         for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->dec_blk[j][i][0]); py[i] = make_stream_params(arena, L->dec_blk[j][i][1]); }
         swf_block_desc bd = level_block_desc(desc, lvl, false);
+        const char* after = nullptr;
+        size_t after_pb = 0;
+        if (packed && j + 1 < n) {
+            swf_block_desc nb = level_block_desc(desc, n - 2 - j, false);
+            if (window_block_packed_bytes(nb) && plan.dec_on[j + 1]) { after = packed + plan.dec[j + 1]; after_pb = window_block_packed_bytes(nb); }
+        }
         SWF_TRY(block_pair4_impl(&bd, px, py, act[lvl][0], act[lvl][1], act[lvl][0], act[lvl][1], B, ls[lvl].Ho, ls[lvl].Wo, scratch, scratch_bytes, stream,
-                                 (packed && plan.dec_on[j]) ? packed + plan.dec[j] : nullptr));
+                                 (packed && plan.dec_on[j]) ? packed + plan.dec[j] : nullptr, after, after_pb));
+        // a deep-level stage cannot warm its successor from inside a block kernel: one small launch does it
+        if (after && window_block_packed_bytes(bd) == 0) SWF_TRY(launch_l2_warm(after, 2 * after_pb, stream));
         swf_patch_params pm[2] = {patch_params(L->dec_patch[j][0]), patch_params(L->dec_patch[j][1])};
         const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
         const float* ins[2] = {act[lvl][0], act[lvl][1]};
