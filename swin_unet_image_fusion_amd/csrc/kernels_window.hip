@@ -2,8 +2,8 @@
 // streams, for 8x8 windows and C in {24, 48, 96}.  Persistent workgroups walk the windows.  C = 24: 512 threads
 // (8 waves, 2 per SIMD), one workgroup per CU, weights resident in LDS, wave w owns 16 token rows of stream w>>2.
 // C = 48 / 96 (TT = 2): 256 threads, wave w owns 32 token rows of stream w>>1, weights come from L2 and every
-// fragment feeds two MFMAs; two workgroups per CU at C = 48, one (one wave per SIMD, 512 registers, rotating MLP
-// weight prefetch) at C = 96.  A wave keeps its rows for every per-token phase (LN1, Q/K/V, proj, LN2, MLP): the
+// fragment feeds two MFMAs; one workgroup per CU (one wave per SIMD, 512 registers, rotating MLP weight prefetch).
+// Every launch ends by touching the next block's packed weights (per-XCD L2 warm-up).  A wave keeps its rows for every per-token phase (LN1, Q/K/V, proj, LN2, MLP): the
 // residual rows live in registers in the MFMA output layout, loaded once from HBM (cyclic shift = index arithmetic)
 // and stored once.  Only attention mixes tokens and needs the two workgroup barriers per window.  HBM traffic per
 // block = read + write of each stream, nothing else.
@@ -1266,7 +1266,7 @@ static int num_cus() {
 template <int C, int HID>
 static int launch_t(const WinArgs& a, int nwin, hipStream_t stream) {
     using G = Geo<C, HID>;
-    // C = 48: two 16-token tiles per wave, 256-thread workgroups, two per CU (67 KB of LDS each)
+    // C = 48 / 96: two 16-token tiles per wave, 256-thread workgroups, one per CU (94 / 145 KB of LDS)
     constexpr int TT = ((C == 48 && SWF_C48_TT2) || (C == 96 && SWF_C96_TT2)) ? 2 : 1;
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
