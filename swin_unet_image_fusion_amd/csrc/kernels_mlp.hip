@@ -48,6 +48,8 @@ struct MlpArgs {
     const float* b1[2]; const float* b2[2];
     float* scratch;          // [stream][split][M][C] partial sums when splits > 1
     int M, HID, splits, nchunks;
+    // optional: LayerNorm of the finished rows (the NEXT block's LN1) as split planes, written by the reduce kernel
+    const float* ln_gamma[2]; const float* ln_beta[2]; bf16* ln_hi[2]; bf16* ln_lo[2];
 };
 
 __device__ __forceinline__ void mma3(f32x16& acc, const bf16x8 wh, const bf16x8 wl, const bf16x8 bh, const bf16x8 bl) {
@@ -333,6 +335,78 @@ __global__ __launch_bounds__(256) void mlp_reduce_kernel(MlpArgs a, int C) {
     }
 }
 
+// The same reduce, one token row per L lanes, followed by the next block's LN1 on the finished row (out_hi / out_lo planes, the
+// operand format of its Q/K/V GEMMs): saves that block's LayerNorm launch.  Same arithmetic, in the same order, as
+// layernorm_vec_kernel (kernels_generic.hip).
+template <int NCH>
+__global__ __launch_bounds__(256) void mlp_reduce_ln_kernel(MlpArgs a, int C, int L) {
+    const int s = blockIdx.y;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tok = gt / L;
+    const int sub = (int)(gt % L);
+    const bool live = tok < a.M;
+    const int chunks = C >> 2;
+    const int64_t total = (int64_t)a.M * C, row = (live ? tok : 0) * C;
+    const float* part = a.scratch + (int64_t)s * a.splits * total + row;
+    float4 v[NCH], gm[NCH], bt[NCH];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = sub + i * L;
+        v[i] = gm[i] = bt[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (live && ch < chunks) {
+            // all loads of the row go out together (the first six partials predicated, not looped), summed in fixed order
+            float4 u[6];
+#pragma unroll
+            for (int k = 0; k < 6; ++k)
+                u[k] = k < a.splits ? *reinterpret_cast<const float4*>(part + k * total + 4 * ch) : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 b = *reinterpret_cast<const float4*>(a.b2[s] + 4 * ch);
+            const float4 x = *reinterpret_cast<const float4*>(a.x[s] + row + 4 * ch);
+            gm[i] = *reinterpret_cast<const float4*>(a.ln_gamma[s] + 4 * ch);
+            bt[i] = *reinterpret_cast<const float4*>(a.ln_beta[s] + 4 * ch);
+            float4 t = u[0];
+#pragma unroll
+            for (int k = 1; k < 6; ++k)
+                if (k < a.splits) { t.x += u[k].x; t.y += u[k].y; t.z += u[k].z; t.w += u[k].w; }
+            for (int k = 6; k < a.splits; ++k) {
+                const float4 w = *reinterpret_cast<const float4*>(part + k * total + 4 * ch);
+                t.x += w.x; t.y += w.y; t.z += w.z; t.w += w.w;
+            }
+            t.x += b.x + x.x; t.y += b.y + x.y; t.z += b.z + x.z; t.w += b.w + x.w;
+            *reinterpret_cast<float4*>(a.out[s] + row + 4 * ch) = t;
+            v[i] = t;
+        }
+        sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+    const float mean = sum / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (sub + i * L < chunks) {
+            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+            q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+        }
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+    if (!live) return;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = sub + i * L;
+        if (ch < chunks) {
+            const float4 g = gm[i], b = bt[i];
+            const float r[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
+            bf16x4 hi, lo;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) { hi[j] = (bf16)r[j]; lo[j] = (bf16)(r[j] - (float)hi[j]); }
+            *reinterpret_cast<bf16x4*>(a.ln_hi[s] + row + 4 * ch) = hi;
+            *reinterpret_cast<bf16x4*>(a.ln_lo[s] + row + 4 * ch) = lo;
+        }
+    }
+}
+
 template <int C>
 int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
     constexpr int lds = (64 * (C + 8) + 64 * (128 + 8)) * 2 * 2;
@@ -347,6 +421,12 @@ int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
     dim3 grid((a.M + 63) / 64, a.splits, nstream);
     hipLaunchKernelGGL((mlp_fused_kernel<C>), grid, dim3(256), lds, stream, a);
     SWF_TRY(check_launch("mlp_fused"));
+    if (a.splits > 1 && a.ln_hi[0]) {
+        constexpr int chunks = C / 4, L = chunks > 32 ? 64 : 32, NCH = (chunks + L - 1) / L;   // as launch_layernorm picks them
+        dim3 rgrid((unsigned)cdiv64((int64_t)a.M * L, 256), nstream);
+        hipLaunchKernelGGL((mlp_reduce_ln_kernel<NCH>), rgrid, dim3(256), 0, stream, a, C, L);
+        return check_launch("mlp_reduce_ln");
+    }
     if (a.splits > 1) {
         dim3 rgrid((unsigned)std::min<int64_t>(cdiv64((int64_t)a.M * C, 1024), 2048), nstream);
         hipLaunchKernelGGL(mlp_reduce_kernel, rgrid, dim3(256), 0, stream, a, C);
@@ -386,6 +466,11 @@ int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream) {
     a.splits = mlp_fused_splits(d.C, d.HID);
     a.nchunks = d.HID / 128 / a.splits;
     a.scratch = d.scratch;
+    if (d.ln_hi[0] && a.splits > 1)
+        for (int s = 0; s < nstream; ++s) {
+            a.ln_gamma[s] = d.ln_gamma[s]; a.ln_beta[s] = d.ln_beta[s];
+            a.ln_hi[s] = reinterpret_cast<bf16*>(d.ln_hi[s]); a.ln_lo[s] = reinterpret_cast<bf16*>(d.ln_lo[s]);
+        }
     if (a.splits > 1 && (!d.scratch || (int64_t)nstream * a.splits * d.M * d.C > d.scratch_floats))
         return fail(SWF_ERR_WORKSPACE, "mlp_fused: scratch too small for %d hidden splits", a.splits);
     switch (d.C) {

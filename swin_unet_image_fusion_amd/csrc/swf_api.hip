@@ -230,7 +230,13 @@ static size_t deep_block_ws(const swf_block_desc* d, int nstream, int B, int H, 
 
 static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                            const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
-                           Carver& ws, hipStream_t stream, const void* packed_x, const void* packed_y) {
+                           Carver& ws, hipStream_t stream, const void* packed_x, const void* packed_y,
+                           const swf_block_stream_params* const* next_p = nullptr, bool* ln1_ready = nullptr) {
+    // `next_p`: stream parameters of the block that runs next on the same workspace with the same shapes (or nullptr).  When the
+    // fused MLP's reduce kernel can, it also writes that block's LN1 planes; `*ln1_ready` reports it, and on entry says whether the
+    // previous block did the same for this one (the planes sit at the same workspace offsets: the carve depends on shapes only).
+    const bool ln1_given = ln1_ready && *ln1_ready;
+    if (ln1_ready) *ln1_ready = false;
     const int nstream = py ? 2 : 1;
     const int64_t N = (int64_t)B * H * W;
     const int C = desc->attn.channels, HD = desc->attn.heads * desc->attn.head_dim, hid = desc->hidden;
@@ -263,9 +269,11 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         wv[s] = deep_block_views(*desc, pk[s]);
     }
     // attention half (a004:29-38 around a002:58-82)
-    LnBatch l1{};
-    for (int s = 0; s < nstream; ++s) l1.p[s] = LnProb{xin[s], nullptr, pp[s]->ln1.gamma, pp[s]->ln1.beta, xn_hi[s], xn_lo[s]};
-    SWF_TRY(launch_layernorm(l1, nstream, N, C, 0, stream));
+    if (!ln1_given) {
+        LnBatch l1{};
+        for (int s = 0; s < nstream; ++s) l1.p[s] = LnProb{xin[s], nullptr, pp[s]->ln1.gamma, pp[s]->ln1.beta, xn_hi[s], xn_lo[s]};
+        SWF_TRY(launch_layernorm(l1, nstream, N, C, 0, stream));
+    }
     SpGemmBatch gq{};
     for (int s = 0; s < nstream; ++s) {
         const int kvs = cross ? 1 - s : s;   // K and V of stream s read the other stream's normalised tokens in a cross block
@@ -301,7 +309,14 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
             md.b1[s] = pp[s]->fc1.bias; md.b2[s] = pp[s]->fc2.bias;
         }
         md.scratch = sk; md.scratch_floats = sk_floats; md.M = (int)N; md.C = C; md.HID = hid;
-        return launch_mlp_fused(md, nstream, stream);
+        const bool ln_next = next_p && ln1_ready && next_p[0] && (nstream == 1 || next_p[1]) && mlp_fused_writes_ln(C, hid);
+        if (ln_next)
+            for (int s = 0; s < nstream; ++s) {
+                md.ln_gamma[s] = next_p[s]->ln1.gamma; md.ln_beta[s] = next_p[s]->ln1.beta; md.ln_hi[s] = xn_hi[s]; md.ln_lo[s] = xn_lo[s];
+            }
+        SWF_TRY(launch_mlp_fused(md, nstream, stream));
+        if (ln_next) *ln1_ready = true;
+        return SWF_OK;
     }
     LnBatch l2{};
     for (int s = 0; s < nstream; ++s) l2.p[s] = LnProb{xout[s], nullptr, pp[s]->ln2.gamma, pp[s]->ln2.beta, xn_hi[s], xn_lo[s]};
@@ -342,7 +357,9 @@ static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_p
                             const swf_block_stream_params* py, const float* x_in, const float* y_in, float* x_out,
                             float* y_out, int B, int H, int W, void* workspace, size_t workspace_bytes,
                             hipStream_t stream, const void* prepacked_x = nullptr, const void* prepacked_y = nullptr,
-                            const void* next_x = nullptr, const void* next_y = nullptr, size_t next_bytes = 0) {
+                            const void* next_x = nullptr, const void* next_y = nullptr, size_t next_bytes = 0,
+                            const swf_block_stream_params* const* next_p = nullptr, bool* ln1_ready = nullptr) {
+    // next_p / ln1_ready: see deep_block_impl; every other path ignores the planes and leaves *ln1_ready false
     if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W)) {
         if (prepacked_x && prepacked_y)   // model path: weights were packed once (swf_model_pack_weights)
             return launch_window_block(*desc, prepacked_x, prepacked_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_x, next_y, next_bytes);
@@ -367,8 +384,9 @@ static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_p
     static const bool no_deep = std::getenv("SWF_NO_DEEP") != nullptr;   // A/B switch for tools/profile_block.py
     if (deep_block_supported(*desc) && !no_deep && tbits % 16 == 0 && aligned16(px) && aligned16(py)) {
         Carver ws(workspace, workspace_bytes);
-        return deep_block_impl(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, stream, prepacked_x, prepacked_y);
+        return deep_block_impl(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, stream, prepacked_x, prepacked_y, next_p, ln1_ready);
     }
+    if (ln1_ready) *ln1_ready = false;
     {
         Carver ws(workspace, workspace_bytes);
         SWF_TRY(attn_halfblock_generic(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, stream));
@@ -668,6 +686,7 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
     const float* xi = x_in;
     const float* yi = y_in;
     const size_t pb = packed ? block_packed_bytes(*desc) : 0;
+    bool ln1_ready = false;   // deep levels: block i's MLP reduce also writes block i+1's LN1 planes
     for (int i = 0; i < 4; ++i) {
         swf_block_desc d = *desc;
         d.cross = i >= 2;          // self pair first, then cross pair (a012:72-73)
@@ -676,8 +695,9 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
         const void* pky = (packed && pb) ? packed + (size_t)(2 * i + 1) * pb : nullptr;
         const void* nkx = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 2) * pb : (i == 3 ? after : nullptr);   // next block: warmed in L2
         const void* nky = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 3) * pb : (i == 3 && after ? after + after_pb : nullptr);
+        const swf_block_stream_params* nxt[2] = {i < 3 ? &px[i + 1] : nullptr, (i < 3 && py) ? &py[i + 1] : nullptr};
         SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream, pkx, pky,
-                                 nkx, nky, i == 3 ? after_pb : 0));
+                                 nkx, nky, i == 3 ? after_pb : 0, i < 3 ? nxt : nullptr, &ln1_ready));
         xi = x_out; yi = y_out;
     }
     return SWF_OK;
