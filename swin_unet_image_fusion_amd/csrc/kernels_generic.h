@@ -73,6 +73,11 @@ int launch_reflect_pad(const float* in, float* out, int B, int H, int W, int C, 
 // [B][Hp][Wp][C] -> [B][Hm][Wm][C] (top-left crop)
 int launch_crop(const PtrPair& pp, int nprob, int B, int Hp, int Wp, int Hm, int Wm, int C, hipStream_t stream);
 // Decoder scatter: out[b][y][x][c] = ELU(Z[(b,y/mh,x/mw)][((y%mh)*mw+x%mw)*Cout+c]) (+ skip)
+// LayerNorm(batch.p[i].in rows of mh*mw*Cout) -> depth-to-space -> ELU (+ pp.aux skip) -> pp.out, one launch; bit-identical to
+// launch_layernorm followed by launch_unmerge_scatter.  Needs Cout % 4 == 0, mh*mw*Cout <= 1024, 16-byte aligned tensors.
+bool ln_unmerge_scatter_supported(const LnBatch& batch, const PtrPair& pp, int nprob, int Cout, int mh, int mw);
+int launch_ln_unmerge_scatter(const LnBatch& batch, const PtrPair& pp, int nprob, int B, int Hm, int Wm, int Cout, int mh, int mw,
+                              int Hout, int Wout, hipStream_t stream);
 int launch_unmerge_scatter(const PtrPair& pp, int nprob, int B, int Hm, int Wm, int Cout, int mh, int mw,
                            int Hout, int Wout, hipStream_t stream);
 
@@ -81,6 +86,9 @@ int launch_head_conv1(const float* x, const float* y, float* tmp, const swf_head
                       int ks, hipStream_t stream);
 int launch_head_conv2(const float* tmp, float* out, const swf_head_params& p, int B, int H, int W, int ks,
                       hipStream_t stream);
+// both convolutions; one fused launch for 3x3 kernels (tmp [B][H][W][2] is only used by the two-kernel path)
+int launch_head(const float* x, const float* y, float* tmp, float* out, const swf_head_params& p, int B, int H, int W, int ks,
+                hipStream_t stream);
 
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);

@@ -834,6 +834,97 @@ __global__ __launch_bounds__(256) void unmerge_scatter_kernel(PtrPair pp, int B,
     }
 }
 
+// LayerNorm over the mh*mw*Cout conv outputs of a merged token, then depth-to-space + ELU (+ skip) in the same launch
+// (a011:107-117): layernorm_vec_kernel's arithmetic, unmerge_scatter_kernel's index map, no normalised intermediate.
+template <int NCH>
+__global__ __launch_bounds__(256) void ln_unmerge_scatter_kernel(LnBatch batch, PtrPair pp, int64_t tokens, int L, int Hm, int Wm,
+                                                                 int Cout, int mh, int mw, int Hout, int Wout) {
+    const LnProb pr = batch.p[blockIdx.y];
+    float* out = pp.out[blockIdx.y];
+    const float* skip = pp.aux[blockIdx.y];
+    const int C = mh * mw * Cout;
+    const int64_t gt = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    const int64_t tok = gt / L;
+    const int sub = (int)(gt % L);
+    const bool live = tok < tokens;
+    const int chunks = C >> 2;
+    const float4* x = reinterpret_cast<const float4*>(pr.in + (live ? tok : 0) * C);
+    float4 v[NCH];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = sub + i * L;
+        v[i] = (live && ch < chunks) ? x[ch] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float mean = s / (float)C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        if (sub + i * L < chunks) {
+            const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, d = v[i].w - mean;
+            q += (a * a + b * b) + (c * c + d * d);
+        }
+    }
+    for (int o = L >> 1; o > 0; o >>= 1) q += __shfl_xor(q, o);
+    const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+    if (!live) return;
+    const int mx = (int)(tok % Wm), t = (int)(tok / Wm), my = t % Hm, b = t / Hm;
+    const float4* g4 = reinterpret_cast<const float4*>(pr.gamma);
+    const float4* b4 = reinterpret_cast<const float4*>(pr.beta);
+#pragma unroll
+    for (int i = 0; i < NCH; ++i) {
+        const int ch = sub + i * L;
+        if (ch < chunks) {
+            const float4 g = g4[ch], bb = b4[ch];
+            float4 r;
+            r.x = elu1((v[i].x - mean) * rstd * g.x + bb.x);
+            r.y = elu1((v[i].y - mean) * rstd * g.y + bb.y);
+            r.z = elu1((v[i].z - mean) * rstd * g.z + bb.z);
+            r.w = elu1((v[i].w - mean) * rstd * g.w + bb.w);
+            const int p = (4 * ch) / Cout, c = (4 * ch) % Cout;   // Cout % 4 == 0: a chunk never straddles sub-pixels
+            const int y = my * mh + p / mw, xo = mx * mw + p % mw;
+            if (y < Hout && xo < Wout) {
+                const int64_t e = (((int64_t)b * Hout + y) * Wout + xo) * Cout + c;
+                if (skip) {
+                    const float4 k = *reinterpret_cast<const float4*>(skip + e);
+                    r.x += k.x; r.y += k.y; r.z += k.z; r.w += k.w;
+                }
+                *reinterpret_cast<float4*>(out + e) = r;
+            }
+        }
+    }
+}
+
+bool ln_unmerge_scatter_supported(const LnBatch& batch, const PtrPair& pp, int nprob, int Cout, int mh, int mw) {
+    const int C = mh * mw * Cout;
+    if (Cout % 4 != 0 || C > 1024) return false;
+    for (int i = 0; i < nprob; ++i) {
+        uintptr_t bits = reinterpret_cast<uintptr_t>(batch.p[i].in) | reinterpret_cast<uintptr_t>(batch.p[i].gamma) |
+                         reinterpret_cast<uintptr_t>(batch.p[i].beta) | reinterpret_cast<uintptr_t>(pp.out[i]);
+        if (pp.aux[i]) bits |= reinterpret_cast<uintptr_t>(pp.aux[i]);
+        if (bits % 16) return false;
+    }
+    return true;
+}
+
+int launch_ln_unmerge_scatter(const LnBatch& batch, const PtrPair& pp, int nprob, int B, int Hm, int Wm, int Cout, int mh, int mw,
+                              int Hout, int Wout, hipStream_t stream) {
+    if (!ln_unmerge_scatter_supported(batch, pp, nprob, Cout, mh, mw)) return fail(SWF_ERR_UNSUPPORTED, "ln_unmerge_scatter: shape / alignment");
+    if ((int64_t)B * Hout * Wout > INT32_MAX || (int64_t)B * Hm * Wm > INT32_MAX) return fail(SWF_ERR_UNSUPPORTED, "ln_unmerge_scatter: more than 2^31 pixels");
+    const int64_t tokens = (int64_t)B * Hm * Wm;
+    const int chunks = mh * mw * Cout / 4;
+    int L = 1;
+    while (L < 64 && L < chunks) L <<= 1;   // as launch_layernorm picks them: same summation order
+    const int nch = cdiv(chunks, L);
+    dim3 grid((unsigned)cdiv64(tokens * L, 256), nprob);
+    if (nch == 1) hipLaunchKernelGGL(ln_unmerge_scatter_kernel<1>, grid, dim3(256), 0, stream, batch, pp, tokens, L, Hm, Wm, Cout, mh, mw, Hout, Wout);
+    else if (nch == 2) hipLaunchKernelGGL(ln_unmerge_scatter_kernel<2>, grid, dim3(256), 0, stream, batch, pp, tokens, L, Hm, Wm, Cout, mh, mw, Hout, Wout);
+    else hipLaunchKernelGGL(ln_unmerge_scatter_kernel<4>, grid, dim3(256), 0, stream, batch, pp, tokens, L, Hm, Wm, Cout, mh, mw, Hout, Wout);
+    return check_launch("ln_unmerge_scatter");
+}
+
 int launch_unmerge_scatter(const PtrPair& pp, int nprob, int B, int Hm, int Wm, int Cout, int mh, int mw, int Hout,
                            int Wout, hipStream_t stream) {
     if ((int64_t)B * Hout * Wout > INT32_MAX) return fail(SWF_ERR_UNSUPPORTED, "unmerge_scatter: more than 2^31 pixels");
@@ -920,6 +1011,83 @@ int launch_head_conv2(const float* tmp, float* out, const swf_head_params& p, in
     dim3 grid((unsigned)std::min<int64_t>(cdiv64(total, 256), 16384));
     hipLaunchKernelGGL(head_conv2_kernel, grid, dim3(256), 0, stream, tmp, out, p, B, H, W, ks);
     return check_launch("head_conv2");
+}
+
+// Both 3x3 convolutions in one launch: a 64x16 output tile per workgroup; the x / y tile (halo 2) and the ELU(BN(conv1)) tile
+// (halo 1) live in LDS, so the two-channel intermediate never reaches HBM.  Out-of-image positions hold the value at the
+// reflected coordinate (what 'reflect' padding reads), computed there with the same tap order as the two kernels above:
+// bit-identical results.
+constexpr int kHeadTW = 64, kHeadTH = 16;
+__global__ __launch_bounds__(256) void head_fused3_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                          float* __restrict__ out, swf_head_params p, int H, int W) {
+    constexpr int TW = kHeadTW, TH = kHeadTH, IW = TW + 4, IH = TH + 4, MW = TW + 2, MH = TH + 2;
+    __shared__ float sx[IH][IW], sy[IH][IW], t0[MH][MW], t1[MH][MW];
+    const int tx0 = blockIdx.x * TW, ty0 = blockIdx.y * TH;
+    const int64_t img = (int64_t)blockIdx.z * H * W;
+    auto refl = [](int i, int n) { return min(max(reflect2(i, n), 0), n - 1); };   // clamp: positions past a partial tile are never used
+    for (int i = threadIdx.x; i < IH * IW; i += 256) {
+        const int iy = i / IW, ix = i % IW;
+        const int64_t s = img + (int64_t)refl(ty0 - 2 + iy, H) * W + refl(tx0 - 2 + ix, W);
+        sx[iy][ix] = x[s];
+        sy[iy][ix] = y[s];
+    }
+    float w1[36], w2[18];
+#pragma unroll
+    for (int i = 0; i < 36; ++i) w1[i] = p.conv1_w[i];
+#pragma unroll
+    for (int i = 0; i < 18; ++i) w2[i] = p.conv2_w[i];
+    const float b10 = p.conv1_b[0], b11 = p.conv1_b[1], b2 = p.conv2_b[0];
+    const float m0 = p.bn_mean[0], m1 = p.bn_mean[1], v0 = p.bn_var[0], v1 = p.bn_var[1];
+    const float g0 = p.bn_gamma[0], g1 = p.bn_gamma[1], be0 = p.bn_beta[0], be1 = p.bn_beta[1];
+    __syncthreads();
+    for (int i = threadIdx.x; i < MH * MW; i += 256) {
+        const int iy = i / MW, ix = i % MW;
+        // centre of the 3x3 patch in LDS coordinates: the (reflected) image position of this intermediate pixel
+        const int cy = min(max(refl(ty0 - 1 + iy, H) - (ty0 - 2), 1), IH - 2), cx = min(max(refl(tx0 - 1 + ix, W) - (tx0 - 2), 1), IW - 2);
+        float a0 = b10, a1 = b11;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const float vx = sx[cy + ky - 1][cx + kx - 1], vy = sy[cy + ky - 1][cx + kx - 1];
+                a0 = fmaf(w1[((0 * 2 + 0) * 3 + ky) * 3 + kx], vx, a0);
+                a0 = fmaf(w1[((0 * 2 + 1) * 3 + ky) * 3 + kx], vy, a0);
+                a1 = fmaf(w1[((1 * 2 + 0) * 3 + ky) * 3 + kx], vx, a1);
+                a1 = fmaf(w1[((1 * 2 + 1) * 3 + ky) * 3 + kx], vy, a1);
+            }
+        a0 = (a0 - m0) / sqrtf(v0 + 1e-5f) * g0 + be0;
+        a1 = (a1 - m1) / sqrtf(v1 + 1e-5f) * g1 + be1;
+        t0[iy][ix] = elu1(a0);
+        t1[iy][ix] = elu1(a1);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < TH * TW; i += 256) {
+        const int iy = i / TW, ix = i % TW;
+        const int py = ty0 + iy, px = tx0 + ix;
+        if (py >= H || px >= W) continue;
+        float a = b2;
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                a = fmaf(w2[(0 * 3 + ky) * 3 + kx], t0[iy + ky][ix + kx], a);
+                a = fmaf(w2[(1 * 3 + ky) * 3 + kx], t1[iy + ky][ix + kx], a);
+            }
+        out[img + (int64_t)py * W + px] = a;
+    }
+}
+
+int launch_head(const float* x, const float* y, float* tmp, float* out, const swf_head_params& p, int B, int H, int W, int ks,
+                hipStream_t stream) {
+    if (ks == 3 && H >= 2 && W >= 2 && B <= 65535) {
+        dim3 grid((unsigned)cdiv(W, kHeadTW), (unsigned)cdiv(H, kHeadTH), (unsigned)B);
+        if (grid.y <= 65535) {
+            hipLaunchKernelGGL(head_fused3_kernel, grid, dim3(256), 0, stream, x, y, out, p, H, W);
+            return check_launch("head_fused3");
+        }
+    }
+    SWF_TRY(launch_head_conv1(x, y, tmp, p, B, H, W, ks, stream));
+    return launch_head_conv2(tmp, out, p, B, H, W, ks, stream);
 }
 
 // ------------------------------------------------------------------------------------------

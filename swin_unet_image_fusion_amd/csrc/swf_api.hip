@@ -501,6 +501,8 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
     }
     if (need_crop) SWF_TRY(launch_crop(cp, nstream, B, Hp, Wp, Hm, Wm, Cin, stream));
     SWF_TRY(launch_gemm(fast, gb, nstream, (int)N, Kz, Cin, Cin, Kz, 0, stream));
+    if (ln_unmerge_scatter_supported(lb, sp, nstream, Cout, mh, mw))   // LN + depth-to-space + ELU (+ skip) in one launch
+        return launch_ln_unmerge_scatter(lb, sp, nstream, B, Hm, Wm, Cout, mh, mw, Hout, Wout, stream);
     SWF_TRY(launch_layernorm(lb, nstream, N, Kz, 0, stream));
     return launch_unmerge_scatter(sp, nstream, B, Hm, Wm, Cout, mh, mw, Hout, Wout, stream);
 }
@@ -878,8 +880,7 @@ int swf_final_head_fwd(const swf_head_params* p, const float* x, const float* y,
     Carver ws(workspace, workspace_bytes);
     float* tmp = ws.floats((int64_t)B * H * W * 2);
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "final_head workspace too small (need %zu B)", ws.used);
-    SWF_TRY(launch_head_conv1(x, y, tmp, *p, B, H, W, ksize, as_stream(stream)));
-    return launch_head_conv2(tmp, out, *p, B, H, W, ksize, as_stream(stream));
+    return launch_head(x, y, tmp, out, *p, B, H, W, ksize, as_stream(stream));
 }
 
 int swf_linear_fwd(const swf_linear* lin, const float* in, const float* residual, float* out, int64_t tokens, int32_t n_in,
@@ -1086,8 +1087,7 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
     swf_head_params hp{arena + L->h_c1w, arena + L->h_c1b, arena + L->h_g, arena + L->h_b, arena + L->h_m, arena + L->h_v,
                        arena + L->h_c2w, arena + L->h_c2b};
     float* tmp = static_cast<float*>(scratch);
-    SWF_TRY(launch_head_conv1(full[0], full[1], tmp, hp, B, H, W, desc->head_ksize, stream));
-    return launch_head_conv2(tmp, out, hp, B, H, W, desc->head_ksize, stream);
+    return launch_head(full[0], full[1], tmp, out, hp, B, H, W, desc->head_ksize, stream);
 }
 
 int swf_model_forward(const swf_model_desc* desc, const float* arena, const float* ir, const float* vis, float* out,

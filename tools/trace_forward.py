@@ -36,8 +36,8 @@ def report(path):
     ks = [t for t in tabs if "kernel_symbol" in t][0]
     rows = list(cur.execute(f"select s.kernel_name, d.start, d.end, d.grid_size_x, d.grid_size_y, d.grid_size_z, d.workgroup_size_x "
                             f"from {kd} d join {ks} s on d.kernel_id = s.id order by d.start"))
-    # last forward = everything after the last but one head_conv2
-    idx = [i for i, r in enumerate(rows) if "head_conv2" in r[0]]
+    # last forward = everything after the last but one head kernel (the last launch of a forward)
+    idx = [i for i, r in enumerate(rows) if "head_conv2" in r[0] or "head_fused3" in r[0]]
     lo = idx[-2] + 1 if len(idx) >= 2 else 0
     fw = rows[lo:idx[-1] + 1]
     t0 = fw[0][1]
