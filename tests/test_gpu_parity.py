@@ -408,3 +408,33 @@ def test_single_path_block_and_pair():
     out = m(x.to(DEV))
     assert isinstance(out, torch.Tensor)
     _close(out, r, 2e-5)
+
+
+@pytest.mark.parametrize("ksize", [3, 5])
+@pytest.mark.parametrize("shape", [(2, 2, 3), (1, 16, 65), (2, 33, 64), (1, 17, 130), (3, 5, 7)])
+def test_final_head_edge_shapes_vs_oracle(shape, ksize):
+    """swf_final_head_fwd (a013:126-152) called directly: the fused 3x3 kernel on maps smaller than, equal to and straddling its
+    64x16 tile (reflect halos crossing tile and image edges), and the two-kernel path for another kernel size."""
+    import ctypes as C
+    from swin_unet_image_fusion_amd import _lib as L
+    from swin_unet_image_fusion_amd.modules import _ptr, _stream
+    b, h, w = shape
+    if ksize // 2 >= min(h, w):
+        pytest.skip("reflect pad >= map (raises, covered by the error-path tests)")
+    gen = torch.Generator().manual_seed(100 * h + w + ksize)
+    sd = {"final_layer.0.weight": torch.randn(2, 2, ksize, ksize, generator=gen) * 0.3, "final_layer.0.bias": torch.randn(2, generator=gen) * 0.1,
+          "final_layer.1.weight": torch.rand(2, generator=gen) + 0.5, "final_layer.1.bias": torch.randn(2, generator=gen) * 0.1,
+          "final_layer.1.running_mean": torch.randn(2, generator=gen) * 0.1, "final_layer.1.running_var": torch.rand(2, generator=gen) + 0.5,
+          "final_layer.3.weight": torch.randn(1, 2, ksize, ksize, generator=gen) * 0.3, "final_layer.3.bias": torch.randn(1, generator=gen) * 0.1}
+    x, y = torch.randn(b, 1, h, w, generator=gen), torch.randn(b, 1, h, w, generator=gen)
+    ref = O.final_head(sd, x, y, ksize)
+    dv = {k: v.to(DEV).contiguous() for k, v in sd.items()}
+    hp = L.HeadParams(_ptr(dv["final_layer.0.weight"]), _ptr(dv["final_layer.0.bias"]), _ptr(dv["final_layer.1.weight"]),
+                      _ptr(dv["final_layer.1.bias"]), _ptr(dv["final_layer.1.running_mean"]), _ptr(dv["final_layer.1.running_var"]),
+                      _ptr(dv["final_layer.3.weight"]), _ptr(dv["final_layer.3.bias"]))
+    xd, yd = x.to(DEV).contiguous(), y.to(DEV).contiguous()     # one channel: NCHW == NHWC
+    out = torch.full((b, 1, h, w), float("nan"), device=DEV)
+    ws = torch.empty(b * h * w * 2 + 64, dtype=torch.float32, device=DEV)
+    L.check(L.lib().swf_final_head_fwd(C.byref(hp), _ptr(xd), _ptr(yd), _ptr(out), b, h, w, ksize, _ptr(ws), ws.numel() * 4,
+                                       _stream(xd.device)))
+    _close(out, ref)
