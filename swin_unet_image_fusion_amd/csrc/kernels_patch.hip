@@ -301,7 +301,7 @@ int launch_cfg(const PatchArgs& a, int nstream, hipStream_t stream) {
     const int ntiles = (a.M + 63) / 64;
     // a few tiles per workgroup amortise the weight staging; at most ~8 resident workgroups per CU
     const int per_cu = std::max(1, std::min(8, 160 * 1024 / lds));
-    const int grid_x = std::max(1, std::min(ntiles, 256 * per_cu));
+    const int grid_x = std::max(1, std::min(ntiles, 256 * per_cu / nstream));   // one resident round over both streams
     hipLaunchKernelGGL((patch_fused_kernel<KS, NT, DEC, VEC>), dim3(grid_x, nstream), dim3(256), lds, stream, a);
     return check_launch("patch_fused");
 }

@@ -464,10 +464,7 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
     const int Kz = mh * mw * Cout;
     const bool need_crop = (Hm != Hp) || (Wm != Wp);
     static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switch
-    // wide outputs on few tokens (level 2 at 256x256: 256 tiles of 192 channels) leave the per-workgroup weight staging
-    // unamortised: the GEMM path below is faster there (measured 49 vs 55 us)
-    const bool few_wide = N < 512 * 64 && Kz > 96;
-    if (fast && !no_fused && !few_wide && patch_fused_supported(Cin, Kz)) {   // one launch: crop -> conv -> LN -> scatter -> ELU (+ skip)
+    if (fast && !no_fused && patch_fused_supported(Cin, Kz)) {   // one launch: crop -> conv -> LN -> scatter -> ELU (+ skip)
         PatchFusedDesc d{};
         for (int s = 0; s < nstream; ++s) {
             d.in[s] = in[s]; d.out[s] = out[s]; d.skip[s] = skip ? skip[s] : nullptr;
