@@ -73,6 +73,10 @@ struct Geo {
     // row stride (bf16) of the packed fc2 weights: an odd multiple of 16 B, so the 16-row fragment reads from LDS (C = 24) are
     // conflict-free (the 192-byte rows of KH = 96 were 4-way conflicted: rows r and r+4 on the same banks)
     static constexpr int LDW2 = KH + 8;
+    // LDS-resident K-major weights with 64-byte rows (C = 24): a plain 16-row fragment read is 2-way conflicted in every
+    // ds_read_b128 lane group ({0-3,12-15,20-27}, ...: rows r and r+4.. share a 64-byte bank quarter).  The pack stores the
+    // 16-byte chunk g of row n at position g ^ wswz(n), which makes all four groups conflict-free (wswz below).
+    static constexpr bool WSWZ = WLDS && KC == 32;
     static constexpr int LDC = KC + 8;                                  // row stride (bf16) of the token-major images: odd multiple of 16 B -> conflict-free b128 reads
     static constexpr int NTC = cceil(C, 16), NTH = cceil(HID, 16);      // 16-wide output tiles
     static constexpr int NH = NTH * 16;
@@ -170,6 +174,21 @@ __device__ __forceinline__ void load_frag(Frag<KSTEPS>& f, const bf16* hi, const
     for (int ks = 0; ks < KSTEPS; ++ks) {
         f.hi[ks] = *reinterpret_cast<const bf16x8*>(hi + row * LD + k0 + ks * 32 + 8 * g);
         f.lo[ks] = *reinterpret_cast<const bf16x8*>(lo + row * LD + k0 + ks * 32 + 8 * g);
+    }
+}
+
+// chunk swizzle of a K-major weight row (Geo::WSWZ): with q = (n >> 2) & 3 the map 0,1,2,3 -> 0,3,2,1 (and any rotation of
+// it by 2: fragments start at rows = 0 or 8 mod 16) gives the lanes {r16 in 0-3,12-15 | g} and {r16 in 4-11 | g^1} of one
+// ds_read_b128 group four different chunk positions inside every 64-byte bank quarter
+__host__ __device__ __forceinline__ constexpr int wswz(int n) { return (-(n >> 2)) & 3; }
+
+template <int KSTEPS, int LD, bool SWZ>
+__device__ __forceinline__ void load_frag_w(Frag<KSTEPS>& f, const bf16* hi, const bf16* lo, int row, int g) {
+    if constexpr (SWZ) {
+        static_assert(KSTEPS == 1, "the chunk swizzle covers one 32-deep k-step");
+        load_frag<KSTEPS, LD>(f, hi, lo, row, g ^ wswz(row));
+    } else {
+        load_frag<KSTEPS, LD>(f, hi, lo, row, g);
     }
 }
 
@@ -362,9 +381,9 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel
                 const int ch4 = nt * 16 + 4 * g;           // this lane's 4 output channels (transposed tiles)
                 const int wrow = nt * 16 + r16 < C ? nt * 16 + r16 : 0;
                 Frag<KS> wq, wk, wv;
-                load_frag<KS, G::KC>(wq, wmat(ws, G::p_wqkv_hi), wmat(ws, G::p_wqkv_lo), wrow, g);
-                load_frag<KS, G::KC>(wk, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), C + wrow, g);
-                load_frag<KS, G::KC>(wv, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), 2 * C + wrow, g);
+                load_frag_w<KS, G::KC, G::WSWZ>(wq, wmat(ws, G::p_wqkv_hi), wmat(ws, G::p_wqkv_lo), wrow, g);
+                load_frag_w<KS, G::KC, G::WSWZ>(wk, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), C + wrow, g);
+                load_frag_w<KS, G::KC, G::WSWZ>(wv, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), 2 * C + wrow, g);
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) {
                     const int trow = (wm0 + tt) * 16;          // first token row of this tile inside the window
@@ -514,7 +533,7 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel
             for (int nt = 0; nt < G::NTC; ++nt) {   // fully unrolled: res[] must be indexed statically
                 const int ch4 = nt * 16 + 4 * g;
                 Frag<KS> wp;
-                load_frag<KS, G::KC>(wp, wmat(ws, G::p_wp_hi), wmat(ws, G::p_wp_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g);
+                load_frag_w<KS, G::KC, G::WSWZ>(wp, wmat(ws, G::p_wp_hi), wmat(ws, G::p_wp_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g);
 #pragma unroll
                 for (int tt = 0; tt < TT; ++tt) {
                     const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
@@ -540,8 +559,8 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel
             if constexpr (ROT) {
                 b1a = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hc * 32 + 4 * g);
                 b1b = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hc * 32 + 16 + 4 * g);
-                load_frag<KS, G::KC>(w1a, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hc * 32 + r16, g);
-                load_frag<KS, G::KC>(w1b, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hc * 32 + 16 + r16, g);
+                load_frag_w<KS, G::KC, G::WSWZ>(w1a, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hc * 32 + r16, g);
+                load_frag_w<KS, G::KC, G::WSWZ>(w1b, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hc * 32 + 16 + r16, g);
             }
         };
         auto req_fc2 = [&](int hc) {
@@ -592,7 +611,7 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel
                     const int hid0 = hc * 32 + t2 * 16;
                     if (hid0 < G::HID) {   // compile-time: tiles wholly in the K padding are just zeros
                         Frag<KS> w1;
-                        load_frag<KS, G::KC>(w1, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hid0 + r16 < G::HID ? hid0 + r16 : 0, g);
+                        load_frag_w<KS, G::KC, G::WSWZ>(w1, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hid0 + r16 < G::HID ? hid0 + r16 : 0, g);
                         const float4 b1 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hid0 + 4 * g);
 #pragma unroll
                         for (int tt = 0; tt < TT; ++tt) {
@@ -1215,19 +1234,21 @@ __global__ __launch_bounds__(256) void pack_block_kernel(PackArgs a) {
         reinterpret_cast<bf16*>(dst + off_hi)[idx] = hi;
         reinterpret_cast<bf16*>(dst + off_lo)[idx] = lo;
     };
+    // position of element (row, k) of a K-major matrix: chunk-swizzled when the rows are read from LDS (Geo::WSWZ)
+    auto kpos = [](int row, int k) { return row * G::KC + (G::WSWZ ? (((k >> 3) ^ wswz(row)) << 3) + (k & 7) : k); };
     for (int i = gtid; i < 3 * C * G::KC; i += gsz) {
         const int which = i / (C * G::KC), n = (i / G::KC) % C, k = i % G::KC;
         float v = k < C ? qkv[which]->weight[n * C + k] : 0.f;
         if (which == 0) v *= qscale;
-        put(G::p_wqkv_hi, G::p_wqkv_lo, i, v);
+        put(G::p_wqkv_hi, G::p_wqkv_lo, kpos(which * C + n, k), v);   // rows of the stacked [3C][KC] matrix
     }
     for (int i = gtid; i < C * G::KC; i += gsz) {
         const int n = i / G::KC, k = i % G::KC;
-        put(G::p_wp_hi, G::p_wp_lo, i, k < C ? p.attn.proj.weight[n * C + k] : 0.f);
+        put(G::p_wp_hi, G::p_wp_lo, kpos(n, k), k < C ? p.attn.proj.weight[n * C + k] : 0.f);
     }
     for (int i = gtid; i < HID * G::KC; i += gsz) {
         const int n = i / G::KC, k = i % G::KC;
-        put(G::p_w1_hi, G::p_w1_lo, i, k < C ? p.fc1.weight[n * C + k] : 0.f);
+        put(G::p_w1_hi, G::p_w1_lo, kpos(n, k), k < C ? p.fc1.weight[n * C + k] : 0.f);
     }
     for (int i = gtid; i < C * G::LDW2; i += gsz) {
         const int n = i / G::LDW2, k = i % G::LDW2;
