@@ -70,9 +70,9 @@ struct Geo {
     static constexpr int NTK = cround(C, 32) / 16;                       // 16-wide tiles spanning the padded row (residual registers per lane = 4 * NTK)
     static_assert(C % 8 == 0, "8 heads of C/8 channels");
     static constexpr int KC = cround(C, 32), KH = cround(HID, 32);      // K extents padded to the MFMA k-step
-    // row stride (bf16) of the packed fc2 weights: an odd multiple of 16 B, so the 16-row fragment reads from LDS (C = 24) are
-    // conflict-free (the 192-byte rows of KH = 96 were 4-way conflicted: rows r and r+4 on the same banks)
-    static constexpr int LDW2 = KH + 8;
+    // row stride (bf16) of the packed fc2 weights: read from L2 (C >= 48) the rows are padded by 16 B (no two rows of a
+    // fragment start on the same 128-byte line offset); LDS-resident (C = 24) they keep KH and are chunk-swizzled (WSWZ below)
+    static constexpr int LDW2 = (C <= 24 && cround(C, 32) == 32) ? KH : KH + 8;   // swizzled instead of padded when LDS-resident (WSWZ)
     // LDS-resident K-major weights with 64-byte rows (C = 24): a plain 16-row fragment read is 2-way conflicted in every
     // ds_read_b128 lane group ({0-3,12-15,20-27}, ...: rows r and r+4.. share a 64-byte bank quarter).  The pack stores the
     // 16-byte chunk g of row n at position g ^ wswz(n), which makes all four groups conflict-free (wswz below).
@@ -641,7 +641,10 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel
 #pragma unroll
                 for (int nt = 0; nt < G::NTC; ++nt) {
                     Frag<1> w2;
-                    load_frag<1, G::LDW2>(w2, wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
+                    {
+                        const int w2row = nt * 16 + r16 < C ? nt * 16 + r16 : 0;
+                        load_frag<1, G::LDW2>(w2, wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), w2row, G::WSWZ ? g ^ wswz(w2row) : g, hc * 32);
+                    }
 #pragma unroll
                     for (int tt = 0; tt < TT; ++tt) out[tt][nt] = mma_bf16x3<1>(w2, hfrag[tt], out[tt][nt]);
                     if ((nt & 1) == 1) SWF_LOAD_FENCE(G);
@@ -1252,7 +1255,9 @@ __global__ __launch_bounds__(256) void pack_block_kernel(PackArgs a) {
     }
     for (int i = gtid; i < C * G::LDW2; i += gsz) {
         const int n = i / G::LDW2, k = i % G::LDW2;
-        put(G::p_w2_hi, G::p_w2_lo, i, k < HID ? p.fc2.weight[n * HID + k] : 0.f);
+        // LDS-resident: chunks swizzled inside every 32-wide k-step (rows are a multiple of 64 bytes); else padded rows
+        const int pos = G::WSWZ ? n * G::LDW2 + (k & ~31) + ((((k >> 3) & 3) ^ wswz(n)) << 3) + (k & 7) : i;
+        put(G::p_w2_hi, G::p_w2_lo, pos, k < HID ? p.fc2.weight[n * HID + k] : 0.f);
     }
     // relative-position bias (a001:113-144) with the shift mask (a001:217-315) folded in, four variants:
     // bit1 = window in the last window row, bit0 = window in the last window column.  Only those windows
