@@ -32,6 +32,11 @@
 #ifndef SWF_C96_TT2
 #define SWF_C96_TT2 1   // C = 96 block kernel: 4 waves x 32 tokens, one wave per SIMD (106 -> 98 us, 79 -> 74 us)
 #endif
+#ifndef SWF_C24_L2
+#define SWF_C24_L2 1    // C = 24, hidden <= 32 (the last decoder stage: hidden 4): weights from L2, 4 waves x 32 tokens, three 51-KB
+                        // workgroups per CU = 3 waves per SIMD (108 -> 99 us).  With hidden 96 the same layout spills 46 registers in
+                        // the MLP and gains nothing (138 vs 131 us), so that shape keeps its LDS-resident weights.
+#endif
 #ifndef SWF_C48_TT2
 #define SWF_C48_TT2 1   // C = 48 block kernel: 32 tokens per wave (see window_block_kernel)
 #endif
@@ -66,13 +71,14 @@ struct Geo {
     // Are both streams' weight sections LDS-resident?  They are at C=24 (2 x 35 KB).  From C=48 on they do not fit
     // next to the window tile (2 x 135 KB); the kernel then reads weight fragments from L2 (all workgroups share
     // the same lines; a wave's fragment loads are address-independent and issue ahead of their MFMAs).
-    static constexpr bool WLDS = C <= 24;
+    static constexpr bool SMALL_L2 = C == 24 && HID <= 32 && SWF_C24_L2;   // see SWF_C24_L2
+    static constexpr bool WLDS = C <= 24 && !SMALL_L2;
     static constexpr int NTK = cround(C, 32) / 16;                       // 16-wide tiles spanning the padded row (residual registers per lane = 4 * NTK)
     static_assert(C % 8 == 0, "8 heads of C/8 channels");
     static constexpr int KC = cround(C, 32), KH = cround(HID, 32);      // K extents padded to the MFMA k-step
     // row stride (bf16) of the packed fc2 weights: read from L2 (C >= 48) the rows are padded by 16 B (no two rows of a
     // fragment start on the same 128-byte line offset); LDS-resident (C = 24) they keep KH and are chunk-swizzled (WSWZ below)
-    static constexpr int LDW2 = (C <= 24 && cround(C, 32) == 32) ? KH : KH + 8;   // swizzled instead of padded when LDS-resident (WSWZ)
+    static constexpr int LDW2 = (WLDS && cround(C, 32) == 32) ? KH : KH + 8;   // swizzled instead of padded when LDS-resident (WSWZ)
     // LDS-resident K-major weights with 64-byte rows (C = 24): a plain 16-row fragment read is 2-way conflicted in every
     // ds_read_b128 lane group ({0-3,12-15,20-27}, ...: rows r and r+4.. share a 64-byte bank quarter).  The pack stores the
     // 16-byte chunk g of row n at position g ^ wswz(n), which makes all four groups conflict-free (wswz below).
@@ -254,7 +260,7 @@ __device__ __forceinline__ void layernorm_regs(const float4 (&res)[G::NTK], bf16
 // 256 threads, wave w owns tokens [32(w&1), +32) of stream w>>1: every weight fragment a wave pulls from L2 feeds two MFMAs
 // (half the L1->register traffic per token, the measured bound of the L2-sourced variants) and two workgroups share a CU.
 template <int C_, int HID_, int TT>
-__global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel(WinArgs args) {
+__global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 1) : 2) void window_block_kernel(WinArgs args) {
     using G = Geo<C_, HID_>;
     constexpr int C = G::C, D = G::D, T = G::T, LDC = G::LDC, KS = G::KC / 32;
     constexpr int NTHR = 512 / TT;              // threads per workgroup
@@ -433,7 +439,7 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel
             const bf16* qrow = qimg + (s * T + 32 * qb + r) * LDC + 8 * hf;
             const bf16* krow0 = kimg + (s * T + r) * LDC + 8 * hf;
             const bf16* krow1 = krow0 + 32 * LDC;
-            constexpr int HEAD_UNROLL = G::NTK <= 2 ? SWF_HEAD_UNROLL_C24 : 1;   // heads in flight while the residual registers are few
+            constexpr int HEAD_UNROLL = (G::NTK <= 2 && TT == 1) ? SWF_HEAD_UNROLL_C24 : 1;   // heads in flight while the residual registers are few
 #pragma unroll HEAD_UNROLL
             for (int hh = 0; hh < 4 * TT; ++hh) {
                 const int head = h0 + hh;
@@ -551,7 +557,7 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? 1 : 2) void window_block_kernel
         // registers to spend): the fc1 fragments (+ bias) of chunk hc+1 are requested as soon as chunk hc's fc1 MFMAs have
         // consumed theirs, the fc2 fragments of chunk hc+1 as soon as chunk hc's fc2 MFMAs have; chunk 0's go out here, under
         // LN2.  Scheduling fences pin the issue points (hipcc otherwise sinks the loads next to their uses).
-        constexpr bool ROT = !G::WLDS && TT == 2 && SWF_MLP_ROTATE && G::HID % 32 == 0;
+        constexpr bool ROT = !G::WLDS && TT == 2 && SWF_MLP_ROTATE && G::HID % 32 == 0 && C > 24;   // C = 24 runs 3 waves per SIMD: no registers to spare
         Frag<ROT ? KS : 1> w1a, w1b;
         Frag<1> w2r[ROT ? G::NTC : 1];
         float4 b1a, b1b;
@@ -1293,7 +1299,8 @@ template <int C, int HID>
 static int launch_t(const WinArgs& a, int nwin, hipStream_t stream) {
     using G = Geo<C, HID>;
     // C = 48 / 96: two 16-token tiles per wave, 256-thread workgroups, one per CU (94 / 145 KB of LDS)
-    constexpr int TT = ((C == 48 && SWF_C48_TT2) || (C == 96 && SWF_C96_TT2)) ? 2 : 1;
+    constexpr int TT = (G::SMALL_L2 || (C == 48 && SWF_C48_TT2) || (C == 96 && SWF_C96_TT2)) ? 2 : 1;
+    constexpr int PER_CU = G::SMALL_L2 ? 3 : 1;   // resident workgroups per CU
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
@@ -1301,7 +1308,7 @@ static int launch_t(const WinArgs& a, int nwin, hipStream_t stream) {
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::l_total);
     });
     if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window_block): %s", hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((window_block_kernel<C, HID, TT>), dim3(std::min(nwin, num_cus())), dim3(512 / TT), G::l_total, stream, a);
+    hipLaunchKernelGGL((window_block_kernel<C, HID, TT>), dim3(std::min(nwin, PER_CU * num_cus())), dim3(512 / TT), G::l_total, stream, a);
     return check_launch("window_block");
 }
 
