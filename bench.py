@@ -72,7 +72,7 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     if nbytes:      # fast tier: weights pre-packed once (as the model path does), each launch = exactly the fused kernel
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         L.check(lib.swf_basic_block_pack(C.byref(desc), C.byref(px), C.byref(py), packed.data_ptr(), nbytes, stream))
-        kname = "swf::window_block_kernel<24, 96, 1> (one launch = level-0 shifted-window BasicBlock, both streams)"
+        kname = "swf::window_block_kernel<24, 96, 2> (one launch = level-0 shifted-window BasicBlock, both streams)"
 
         def run():
             L.check(lib.swf_basic_block_fwd_packed(C.byref(desc), packed.data_ptr(), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy),
@@ -103,7 +103,7 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE / WRITE_SIZE collected in
     # separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes); only valid for the default workload
     traffic = None
-    tj = os.path.join(REPO, "profiles", "r01r_traffic.json")
+    tj = os.path.join(REPO, "profiles", "r01x_traffic.json")
     if os.path.exists(tj) and batch == 16 and size == 256 and c == 24 and precision == "fast":
         with open(tj) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")

@@ -33,9 +33,10 @@
 #define SWF_C96_TT2 1   // C = 96 block kernel: 4 waves x 32 tokens, one wave per SIMD (106 -> 98 us, 79 -> 74 us)
 #endif
 #ifndef SWF_C24_L2
-#define SWF_C24_L2 1    // C = 24, hidden <= 32 (the last decoder stage: hidden 4): weights from L2, 4 waves x 32 tokens, three 51-KB
-                        // workgroups per CU = 3 waves per SIMD (108 -> 99 us).  With hidden 96 the same layout spills 46 registers in
-                        // the MLP and gains nothing (138 vs 131 us), so that shape keeps its LDS-resident weights.
+#define SWF_C24_L2 1    // C = 24 (level 0): weights from L2 instead of LDS, 4 waves x 32 tokens, three 51-KB workgroups per CU = 3 waves
+                        // per SIMD at 168 registers (the 32 bias registers are reloaded per window so they are dead outside the
+                        // attention phase).  hidden 96: 133 -> 124 us, hidden 4: 108 -> 96 us per block.  Level 0 was short of
+                        // independent waves (VALU busy 50 %, waves waiting 43 %), not of LDS bandwidth.
 #endif
 #ifndef SWF_C48_TT2
 #define SWF_C48_TT2 1   // C = 48 block kernel: 32 tokens per wave (see window_block_kernel)
@@ -71,7 +72,7 @@ struct Geo {
     // Are both streams' weight sections LDS-resident?  They are at C=24 (2 x 35 KB).  From C=48 on they do not fit
     // next to the window tile (2 x 135 KB); the kernel then reads weight fragments from L2 (all workgroups share
     // the same lines; a wave's fragment loads are address-independent and issue ahead of their MFMAs).
-    static constexpr bool SMALL_L2 = C == 24 && HID <= 32 && SWF_C24_L2;   // see SWF_C24_L2
+    static constexpr bool SMALL_L2 = C == 24 && SWF_C24_L2;   // see SWF_C24_L2
     static constexpr bool WLDS = C <= 24 && !SMALL_L2;
     static constexpr int NTK = cround(C, 32) / 16;                       // 16-wide tiles spanning the padded row (residual registers per lane = 4 * NTK)
     static_assert(C % 8 == 0, "8 heads of C/8 channels");
@@ -428,7 +429,9 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
             const int s = ws, qb = TT == 1 ? (wave >> 1) & 1 : wave & 1, h0 = TT == 1 ? (wave & 1) * 4 : 0;
             const int r = lane & 31, hf = lane >> 5;
             const int variant = args.shift ? ((wy == nwy - 1) * 2 + (wx == nwx - 1)) : 0;
-            if (variant != cur_variant) {   // wave-uniform; only edge windows of shifted blocks differ
+            // SMALL_L2 (3 waves per SIMD, 168 registers): the 32 bias registers are reloaded for every window (L2 hits) so they
+            // are dead outside the attention phase
+            if (G::SMALL_L2 || variant != cur_variant) {   // wave-uniform; only edge windows of shifted blocks differ
                 cur_variant = variant;
                 const float* bias4 = reinterpret_cast<const float*>(args.packed[s] + G::p_bias4) + variant * T * T;
 #pragma unroll
