@@ -38,6 +38,11 @@
                         // attention phase).  hidden 96: 133 -> 124 us, hidden 4: 108 -> 96 us per block.  Level 0 was short of
                         // independent waves (VALU busy 50 %, waves waiting 43 %), not of LDS bandwidth.
 #endif
+#ifndef SWF_C48_TWO_WG
+#define SWF_C48_TWO_WG 1   // C = 48: no separate Q image (Q rows live in the wave's own, by then dead, A-lo rows) -> 74 KB tile, two
+                           // workgroups per CU = 2 waves per SIMD at 256 registers, instead of one 512-register workgroup with the
+                           // rotating MLP prefetch
+#endif
 #ifndef SWF_C48_TT2
 #define SWF_C48_TT2 1   // C = 48 block kernel: 32 tokens per wave (see window_block_kernel)
 #endif
@@ -107,8 +112,12 @@ struct Geo {
     static constexpr size_t img = size_t(2) * T * LDC * 2;                // one token-major bf16 image [2 streams][64][LDC]
     static constexpr size_t l_ahi = 0;                                    // A image (xn / O / xn2 / hidden chunk), hi and lo parts
     static constexpr size_t l_alo = l_ahi + img;
-    static constexpr size_t l_q = l_alo + img;                            // Q (pre-scaled) and K, bf16, all channels of a token in one row
-    static constexpr size_t l_k = l_q + img;
+    // QALO: in the 32-tokens-per-wave layout a wave's queries are its own tokens and its own A rows are dead between the Q/K/V
+    // projections (x fragments sit in registers) and the O stores; head h's O-lo store overwrites only head h's Q channels, which
+    // were consumed by then (the other heads' k-steps mask them out).  So Q is written into the A-lo rows: one image less.
+    static constexpr bool QALO = C == 48 && SWF_C48_TWO_WG && SWF_C48_TT2;
+    static constexpr size_t l_q = QALO ? l_alo : l_alo + img;              // Q (pre-scaled) and K, bf16, all channels of a token in one row
+    static constexpr size_t l_k = l_alo + img + (QALO ? 0 : img);
     static constexpr size_t l_vt = l_k + img;                             // fp16 [2][C] x VRS: V^T, keys in MFMA k order
     static constexpr int ONES_ROW = 2 * C;                                // extra V^T row of 1.0: its product with P^T is the softmax denominator
     static constexpr size_t l_mask = l_vt + size_t(2 * C + 1) * VRS * 2;  // [8 heads][NKS][2 lane halves] x 16 B: channel masks of a head
@@ -261,7 +270,7 @@ __device__ __forceinline__ void layernorm_regs(const float4 (&res)[G::NTK], bf16
 // 256 threads, wave w owns tokens [32(w&1), +32) of stream w>>1: every weight fragment a wave pulls from L2 feeds two MFMAs
 // (half the L1->register traffic per token, the measured bound of the L2-sourced variants) and two workgroups share a CU.
 template <int C_, int HID_, int TT>
-__global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 1) : 2) void window_block_kernel(WinArgs args) {
+__global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : (Geo<C_, HID_>::QALO ? 2 : 1)) : 2) void window_block_kernel(WinArgs args) {
     using G = Geo<C_, HID_>;
     constexpr int C = G::C, D = G::D, T = G::T, LDC = G::LDC, KS = G::KC / 32;
     constexpr int NTHR = 512 / TT;              // threads per workgroup
@@ -560,7 +569,7 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
         // registers to spend): the fc1 fragments (+ bias) of chunk hc+1 are requested as soon as chunk hc's fc1 MFMAs have
         // consumed theirs, the fc2 fragments of chunk hc+1 as soon as chunk hc's fc2 MFMAs have; chunk 0's go out here, under
         // LN2.  Scheduling fences pin the issue points (hipcc otherwise sinks the loads next to their uses).
-        constexpr bool ROT = !G::WLDS && TT == 2 && SWF_MLP_ROTATE && G::HID % 32 == 0 && C > 24;   // C = 24 runs 3 waves per SIMD: no registers to spare
+        constexpr bool ROT = !G::WLDS && TT == 2 && SWF_MLP_ROTATE && G::HID % 32 == 0 && C > 24 && !G::QALO;   // C = 24 runs 3 waves per SIMD: no registers to spare
         Frag<ROT ? KS : 1> w1a, w1b;
         Frag<1> w2r[ROT ? G::NTC : 1];
         float4 b1a, b1b;
@@ -607,8 +616,10 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
             // two chunk buffers so consecutive chunks do not serialise on one LDS region: the wave's A rows, and
             // the Q / K rows it wrote for this window (dead since the post-attention barrier; the projections of
             // the next window rewrite them, K padding included)
-            bf16* hb_hi[2] = {my_ahi, qimg + (ws * T + wm0 * 16) * LDC};
-            bf16* hb_lo[2] = {my_alo, kimg + ((args.cross ? 1 - ws : ws) * T + wm0 * 16) * LDC};
+            // (QALO: no Q image — both halves of the second buffer share the K rows, hi in columns 0-31, lo in 32-63)
+            bf16* const krows = kimg + ((args.cross ? 1 - ws : ws) * T + wm0 * 16) * LDC;
+            bf16* hb_hi[2] = {my_ahi, G::QALO ? krows : qimg + (ws * T + wm0 * 16) * LDC};
+            bf16* hb_lo[2] = {my_alo, G::QALO ? krows + 32 : krows};
             if constexpr (!ROT) {
             constexpr int HC_UNROLL = G::WLDS ? G::KH / 32 : (ROOMY ? 3 : 2);   // L2-sourced weights: full unrolling hoists every fragment load and spills
 #pragma unroll HC_UNROLL
@@ -1303,7 +1314,7 @@ static int launch_t(const WinArgs& a, int nwin, hipStream_t stream) {
     using G = Geo<C, HID>;
     // C = 48 / 96: two 16-token tiles per wave, 256-thread workgroups, one per CU (94 / 145 KB of LDS)
     constexpr int TT = (G::SMALL_L2 || (C == 48 && SWF_C48_TT2) || (C == 96 && SWF_C96_TT2)) ? 2 : 1;
-    constexpr int PER_CU = G::SMALL_L2 ? 3 : 1;   // resident workgroups per CU
+    constexpr int PER_CU = G::SMALL_L2 ? 3 : (G::QALO ? 2 : 1);   // resident workgroups per CU
     static std::once_flag once;
     static hipError_t attr_err = hipSuccess;
     std::call_once(once, [] {
