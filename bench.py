@@ -103,7 +103,7 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE / WRITE_SIZE collected in
     # separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes); only valid for the default workload
     traffic = None
-    tj = os.path.join(REPO, "profiles", "r01x_traffic.json")
+    tj = os.path.join(REPO, "profiles", "r01z_traffic.json")
     if os.path.exists(tj) and batch == 16 and size == 256 and c == 24 and precision == "fast":
         with open(tj) as f:
             traffic = json.load(f).get("hbm_bytes_per_launch")

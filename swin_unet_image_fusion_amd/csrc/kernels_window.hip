@@ -359,7 +359,10 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
     bf16* my_alo = alo + (ws * T + wm0 * 16) * LDC;
 
     int win = blockIdx.x;
-    if (win < nwin) SWF_PREFETCH(win);
+    // three workgroups per CU (SMALL_L2): the other waves cover a window's load latency and the 16 prefetch registers are
+    // the difference between spilling and not, so the rows are loaded at the top of their own window
+    constexpr bool PREFETCH_AHEAD = !G::SMALL_L2;
+    if (PREFETCH_AHEAD && win < nwin) SWF_PREFETCH(win);
     int cur_variant = -1;
     f32x16 bfr[2];   // relative-position bias (+mask) of this wave's (stream, query block), S^T layout, exp2 units
     __syncthreads();
@@ -368,11 +371,12 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
         const int wrem = win % (nwx * nwy);
         const int wy = wrem / nwx, wx = wrem % nwx;
         // ---- own rows: prefetched registers become the residual; start fetching the next window ----
+        if constexpr (!PREFETCH_AHEAD) SWF_PREFETCH(win);
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt)
 #pragma unroll
             for (int nt = 0; nt < NTK; ++nt) res[tt][nt] = pre[tt][nt];
-        if (win + (int)gridDim.x < nwin) SWF_PREFETCH(win + gridDim.x);
+        if (PREFETCH_AHEAD && win + (int)gridDim.x < nwin) SWF_PREFETCH(win + gridDim.x);
 
         SWF_WPROBE(0);
 #ifdef SWF_WIN_PROBE
