@@ -361,7 +361,7 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
     int win = blockIdx.x;
     // three workgroups per CU (SMALL_L2): the other waves cover a window's load latency and the 16 prefetch registers are
     // the difference between spilling and not, so the rows are loaded at the top of their own window
-    constexpr bool PREFETCH_AHEAD = !G::SMALL_L2;
+    constexpr bool PREFETCH_AHEAD = !G::SMALL_L2 && !G::QALO;
     if (PREFETCH_AHEAD && win < nwin) SWF_PREFETCH(win);
     int cur_variant = -1;
     f32x16 bfr[2];   // relative-position bias (+mask) of this wave's (stream, query block), S^T layout, exp2 units
