@@ -29,6 +29,7 @@ from torch import nn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 BYTES_PER_ELEM = 4          # the residual stream is stored fp32 (DESIGN.md "Data layout")
+TRAFFIC_FILE = "r01z_traffic.json"   # committed PMC summary of the level-0 block kernel (tools/pmc_traffic.sh)
 
 
 def parse():
@@ -72,7 +73,8 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     if nbytes:      # fast tier: weights pre-packed once (as the model path does), each launch = exactly the fused kernel
         packed = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         L.check(lib.swf_basic_block_pack(C.byref(desc), C.byref(px), C.byref(py), packed.data_ptr(), nbytes, stream))
-        kname = "swf::window_block_kernel<24, 96, 2> (one launch = level-0 shifted-window BasicBlock, both streams)"
+        kname = (f"fused window-attention BasicBlock kernel, C={c} hidden={blk.mlp_hidden_dims} win={blk.window_size[0]} "
+                 "(one launch = level-0 shifted-window BasicBlock, both streams; kernel symbol in profiles/)")
 
         def run():
             L.check(lib.swf_basic_block_fwd_packed(C.byref(desc), packed.data_ptr(), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy),
@@ -102,13 +104,16 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     achieved = alg_bytes / (ms * 1e-3) / 1e9
     # HBM bytes per launch from the committed PMC passes (profiles/*_traffic.json: FETCH_SIZE / WRITE_SIZE collected in
     # separate rocprofv3 runs and corrected as MI355X_MICROARCH.md prescribes); only valid for the default workload
-    traffic = None
-    tj = os.path.join(REPO, "profiles", "r01z_traffic.json")
-    if os.path.exists(tj) and batch == 16 and size == 256 and c == 24 and precision == "fast":
+    # (PMC counters cannot be read in-process: this field is a constant of the named file, not a measurement of this run)
+    traffic, traffic_source = None, None
+    tj = os.path.join(REPO, "profiles", TRAFFIC_FILE)
+    if os.path.exists(tj) and batch == 16 and size == 256 and c == 24 and precision == "fast" and blk.window_size[0] == 8:
         with open(tj) as f:
-            traffic = json.load(f).get("hbm_bytes_per_launch")
+            rec = json.load(f)
+        traffic = rec.get("hbm_bytes_per_launch")
+        traffic_source = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {rec.get('kernel', 'the level-0 block kernel')})"
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic,
+            "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": kname,
             "ms_per_launch": round(ms, 4), "algorithmic_bytes": alg_bytes, "bytes_per_elem": BYTES_PER_ELEM}
 
@@ -134,7 +139,21 @@ def cpu_baseline(cfg, size, pairs, iters):
             O.model_forward(sd, cfg, ir, vis)
             best = min(best, time.perf_counter() - t)
     return {"value": round(pairs / best, 3), "unit": "pairs/s", "cores": threads, "kind": "port",
-            "sample": f"{iters} forwards of {pairs} pairs {size}x{size} (min), fp32, torch CPU oracle, {threads} threads"}
+            "sample": f"{iters} forwards of {pairs} pairs {size}x{size} (min), fp32, torch CPU oracle, {threads} threads; "
+                      "the oracle is a port: it ran at ~0.85x the reference's own speed where both could be timed "
+                      "(build container, 8 threads: 1.57 vs 1.83 pairs/s)"}
+
+
+def baseline_config_label(args, cfg, world):
+    """Which BASELINE.json config (0-based index into `configs`) this run is, derived from the arguments."""
+    w = cfg.window_size[0]
+    if cfg.n_levels == 5 and w == 8 and args.size == 256 and args.batch == 16:
+        return "BASELINE configs[3], 8 GPUs" if world == 8 else ("BASELINE configs[1]" if world == 1 else f"BASELINE configs[3] shard size on {world} GPUs")
+    if cfg.n_levels == 5 and w == 8 and args.size == 512 and args.batch == 16 and world == 1:
+        return "BASELINE configs[2]"
+    if cfg.n_levels == 5 and w == 16 and args.size == 1024 and args.batch == 8 and world == 1:
+        return "BASELINE configs[4]"
+    return "not a BASELINE config"
 
 
 def main():
@@ -189,6 +208,11 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert fused.shape[0] == args.batch * world and bool(torch.isfinite(fused).all())
+    # the timed path is the hipGraph replay: check it against one eager forward of the same inputs before reporting it
+    graph_equals_eager = None
+    if runner.graph_active:
+        graph_equals_eager = bool(torch.equal(runner.local_forward(ir, vis), model(ir, vis)))
+        assert graph_equals_eager, "hipGraph replay differs from the eager forward"
 
     if rank == 0:
         total_pairs = args.batch * world * args.steps
@@ -198,9 +222,11 @@ def main():
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "fast" else "f32", "data": "synthetic",
             "config": {"workload": f"B={args.batch}/GPU {args.size}x{args.size} IR/visible pairs, win={cfg.window_size[0]}, "
-                                   f"5-level Swin-UNet fusion forward (BASELINE configs[1]; configs[3] at N=8)",
+                                   f"{cfg.n_levels}-level Swin-UNet fusion forward ({baseline_config_label(args, cfg, world)})",
                        "global_batch": args.batch * world, "precision_mode": args.precision,
-                       "residual_stream": "fp32", "hip_graph": runner.graph_active,
+                       "arithmetic": "linear layers split-bf16 (bf16x3) MFMA, QK^T bf16 MFMA, P.V fp16 MFMA, everything else fp32"
+                                     if args.precision == "fast" else "exact fp32 (f32-input MFMA)",
+                       "residual_stream": "fp32", "hip_graph": runner.graph_active, "graph_equals_eager": graph_equals_eager,
                        "collective": "rccl all_gather of the fused output" if world > 1 else "none",
                        "weights": "random-init (numpy PCG64 recipe, seed 0)"},
         }

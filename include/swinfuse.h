@@ -232,6 +232,19 @@ int swf_model_forward_packed(const swf_model_desc* desc, const float* arena, con
                              const float* ir, const float* vis, float* out, int32_t B, int32_t H, int32_t W,
                              void* workspace, size_t workspace_bytes, swf_stream_t stream);
 
+/* First-forward variant: additionally reports, per cross-attention block, whether its two input streams were identical
+ * everywhere — the condition on which the reference prints a message and calls exit() on a model's first forward
+ * (a005_BasicBlock.py:98-118, `(x == y).all()`).  cross_equal_flags: device int32[4 * levels], index
+ * 2*stage + {0: plain-window cross block, 1: shifted-window cross block}, stages = encoder 0..levels-1 then decoder
+ * 0..levels-1; 1 = identical inputs, 0 = inputs differ.  `packed` may be NULL (weights are then packed per call).  The
+ * caller reads the flags back after synchronising and raises; the forward itself always completes. */
+int swf_model_forward_checked(const swf_model_desc* desc, const float* arena, const void* packed,
+                              const float* ir, const float* vis, float* out, int32_t B, int32_t H, int32_t W,
+                              void* workspace, size_t workspace_bytes, int32_t* cross_equal_flags, swf_stream_t stream);
+/* *flag (device int32) = 1 if a[i] == b[i] for every i < count, else 0 (torch semantics: NaN != NaN).  The first-call
+ * test of BasicBlock / SelfAndCrossBlockPair (a005:111-113) without a device->host copy of the tensors. */
+int swf_tensors_equal(const float* a, const float* b, int64_t count, int32_t* flag, swf_stream_t stream);
+
 /* ---- colour-space steps either side of the model in the reference's inference script ------
  * a015_dataset.py:73-93 / a017_test.py:68,83-88.  OpenCV's 8-bit fixed-point BGR->YCrCb and float YCrCb->RGB,
  * restated from its published formulas (cv2 itself is not available to this build). */

@@ -35,6 +35,7 @@ from a005_BasicBlock import BasicBlock                      # noqa: E402
 from a006_PaddingOperation import MyPadding                 # noqa: E402
 from a010_StateRecorder import StateRecorder                # noqa: E402
 from a011_PatchOperation import PatchMergingAndLinearLayer  # noqa: E402
+from a009_NormalAndShiftWinsBlockPair import NormalAndShiftWinsBlockPair  # noqa: E402
 from a012_SelfAndCrossBlockPair import SelfAndCrossBlockPair  # noqa: E402
 from a013_ModelDefinition import MyModel                    # noqa: E402
 
@@ -58,6 +59,9 @@ def key_table(module):
 
 
 def save(name, meta, **arrays):
+    only = os.environ.get("GOLDEN_ONLY")     # comma-separated fixture names: leave every other file untouched
+    if only and name not in only.split(","):
+        return
     meta = dict(meta)
     np.savez_compressed(os.path.join(OUT, name + ".npz"), meta=np.array(json.dumps(meta)),
                         **{k: v.numpy() if isinstance(v, torch.Tensor) else v for k, v in arrays.items()})
@@ -113,6 +117,23 @@ def gen_blocks():
         kw_meta = {k: v for k, v in kw.items() if k != "mlp_activation_func"}
         save(name, dict(kind="basic_block", ctor=kw_meta, in_shape=[b, c, h, w], seed_x=201, seed_y=202,
                         weight_seed=12, flavor="stress", keys=key_table(m)), expected_x=ox, expected_y=oy)
+
+    # NormalAndShiftWinsBlockPair (a009:90-109): plain-window block then shifted-window block, self or cross
+    for name, c, nh, d, win, hid, (b, h, w), cross in [
+        ("nswbp_c8_w4_self", 8, 2, 4, (4, 4), 32, (2, 8, 12), False),
+        ("nswbp_c24_w8_cross", 24, 8, 3, (8, 8), 96, (1, 16, 24), True),
+    ]:
+        kw = dict(in_out_dims=c, num_heads=nh, dims_per_head=d, window_size=win, use_dual_path=True, use_cross_attr=cross,
+                  use_qkv_bias=True, attention_drop_ratio=0.0, linear_after_att_drop_ratio=0.0,
+                  mlp_hidden_dims=hid, mlp_activation_func=nn.ELU(inplace=True), mlp_drop_ratio=0.0)
+        m = NormalAndShiftWinsBlockPair(**kw).eval()
+        load_recipe_into(m, seed=15, flavor="stress")
+        x, y = randn((b, c, h, w), 351), randn((b, c, h, w), 352)
+        ox, oy = m(x.clone(), y.clone())
+        kw_meta = {k: v for k, v in kw.items() if k != "mlp_activation_func"}
+        save(name, dict(kind="normal_and_shift_block_pair", ctor=kw_meta, in_shape=[b, c, h, w], seed_x=351,
+                        seed_y=352, weight_seed=15, flavor="stress", keys=key_table(m)),
+             expected_x=ox, expected_y=oy)
 
     for name, c, nh, d, win, hid, (b, h, w) in [
         ("scbp_c8_w4", 8, 2, 4, (4, 4), 32, (2, 8, 8)),
@@ -176,6 +197,8 @@ MODEL_CASES = [
     ("model_win7_200", "win7", (1, 200, 200), "default"),                   # a013:427 smoke-loop size
     ("model_win16_512", "win16", (1, 512, 512), "default"),                 # BASELINE config 5 window
     ("model_win8_b2_128x192", "win8_4stage", (2, 128, 192), "stress"),      # deepest map 8x12 -> pad to 8x16
+    ("model_win8_512_default", "win8", (1, 512, 512), "default"),           # BASELINE config 3 shape, B=1
+    ("model_win16_1024_default", "win16", (1, 1024, 1024), "default"),      # BASELINE config 5 shape, B=1
 ]
 
 

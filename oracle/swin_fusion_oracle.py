@@ -154,12 +154,19 @@ def basic_block(sd: State, prefix: str, x: Tensor, y: Tensor, *, cross: bool, sh
     return x + mx, y + my
 
 
+def normal_and_shift_block_pair(sd: State, prefix: str, x: Tensor, y: Tensor, *, cross: bool, **kw) -> Tuple[Tensor, Tensor]:
+    """NormalAndShiftWinsBlockPair.forward (a009_NormalAndShiftWinsBlockPair.py:90-109): the plain-window
+    BasicBlock, then the shifted-window BasicBlock (a009:102-105)."""
+    for blk, shift in (("normal_window_block.", False), ("shifted_window_block.", True)):
+        x, y = basic_block(sd, prefix + blk, x, y, cross=cross, shift=shift, **kw)
+    return x, y
+
+
 def self_and_cross_block_pair(sd: State, prefix: str, x: Tensor, y: Tensor, **kw) -> Tuple[Tensor, Tensor]:
     """SelfAndCrossBlockPair.forward (a012:70-78) = self pair then cross pair, each pair =
     normal-window block then shifted-window block (a009:90-109)."""
     for group, cross in (("self_att_block.", False), ("cross_att_block.", True)):
-        for blk, shift in (("normal_window_block.", False), ("shifted_window_block.", True)):
-            x, y = basic_block(sd, prefix + group + blk, x, y, cross=cross, shift=shift, **kw)
+        x, y = normal_and_shift_block_pair(sd, prefix + group, x, y, cross=cross, **kw)
     return x, y
 
 

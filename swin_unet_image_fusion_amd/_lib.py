@@ -12,7 +12,7 @@ import os
 from typing import Optional
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswinfuse.so")
+LIB_PATH = os.environ.get("SWF_LIB_PATH") or os.path.join(_HERE, "libswinfuse.so")   # SWF_LIB_PATH: A/B builds of the library
 
 SWF_MAX_LEVELS = 8
 PREC_FP32, PREC_FAST = 0, 1
@@ -104,6 +104,8 @@ SIGNATURES = {
     "swf_model_packed_bytes": (_sz, [P(ModelDesc)]),
     "swf_model_pack_weights": (C.c_int, [P(ModelDesc), _vp, _vp, _sz, _vp]),
     "swf_model_forward_packed": (C.c_int, [P(ModelDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_model_forward_checked": (C.c_int, [P(ModelDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
+    "swf_tensors_equal": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }
 
 _lib: Optional[C.CDLL] = None

@@ -90,6 +90,10 @@ int launch_head_conv2(const float* tmp, float* out, const swf_head_params& p, in
 int launch_head(const float* x, const float* y, float* tmp, float* out, const swf_head_params& p, int B, int H, int W, int ks,
                 hipStream_t stream);
 
+// *flag (device, pre-set to 1 by the caller) is cleared when a[i] != b[i] for any i < n: the reference's first-call
+// `(x == y).all()` test in front of a cross-attention block (a005_BasicBlock.py:111-113); NaN != NaN as in torch
+int launch_all_equal(const float* a, const float* b, int64_t n, int32_t* flag, hipStream_t stream);
+
 int launch_nchw_to_nhwc(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);
 int launch_nhwc_to_nchw(const float* in, float* out, int B, int C, int H, int W, hipStream_t stream);
 

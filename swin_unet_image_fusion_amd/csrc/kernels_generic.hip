@@ -1091,6 +1091,24 @@ int launch_head(const float* x, const float* y, float* tmp, float* out, const sw
 }
 
 // ------------------------------------------------------------------------------------------
+// (x == y).all() in front of a cross-attention block on a model's first forward (a005:111-113): the flag (pre-set
+// to 1) is cleared by any lane that finds a difference — a benign race, every writer stores 0
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void all_equal_kernel(const float* __restrict__ a, const float* __restrict__ b, int64_t n, int32_t* flag) {
+    bool diff = false;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) diff |= a[i] != b[i];
+    if (diff) *flag = 0;
+}
+
+int launch_all_equal(const float* a, const float* b, int64_t n, int32_t* flag, hipStream_t stream) {
+    if (!a || !b || !flag) return fail(SWF_ERR_NULL, "all_equal: NULL argument");
+    if (n <= 0) return fail(SWF_ERR_BAD_SHAPE, "all_equal: empty tensor");
+    const int grid = (int)std::min<int64_t>(cdiv64(n, 256), 2048);
+    hipLaunchKernelGGL(all_equal_kernel, dim3(grid), dim3(256), 0, stream, a, b, n, flag);
+    return check_launch("all_equal");
+}
+
+// ------------------------------------------------------------------------------------------
 // NCHW <-> NHWC through a 32x32 LDS tile (both sides coalesced)
 // ------------------------------------------------------------------------------------------
 // in viewed as [B][R][S] -> out [B][S][R]

@@ -1,0 +1,618 @@
+// Level-0 fused BasicBlock (a005:127-145) for gfx950: C = 24, 8 heads x 3 channels, 8x8 windows, hidden 96 (encoder) or 4
+// (decoder) — the full-resolution maps, where a block is 2 x 262 144 tokens of 96 bytes and the kernel must look like a
+// streaming kernel.  ONE launch = one BasicBlock for both modality streams.
+//
+// Design: activations never leave registers.  A 256-thread workgroup owns one window; wave w owns the 32 tokens
+// [32*(w&1), +32) of stream w>>1 for the WHOLE block (LayerNorms, Q/K/V, attention for its 32 queries, projection, MLP).
+// Every contraction runs on the 32x32x16 MFMAs, and every operand that is produced by one MFMA and consumed by the next is
+// used where it lands: the C/D map of a 32x32 tile (lane = column, register i of lane half hf = row rho(i, hf)) is also a
+// legal B-operand map (lane = column, element j of k-step s = k index), because a contraction may enumerate its k index in
+// any order as long as both operands agree — so the weight images are packed with their k columns in rho order
+// (pack24_kernel) and LayerNorm output, attention output and hidden activations go from accumulator registers to the next
+// MFMA with only the split into bf16 hi/lo parts in between.  No activation tile, no LayerNorm image, no hidden-chunk image
+// in LDS; the only LDS traffic is the K / V^T operand images that the two waves of a stream exchange (1 KB fragments,
+// lane-linear, conflict-free) and one workgroup barrier per window (images are double-buffered across windows).
+//
+//  * Q, K: rows are "virtual channels" 4*head + c (c < 3; row 4*head+3 is a zero row), so that the packed f16 pairs of the
+//    accumulator are directly the operand fragments of S^T = K.Q^T: k-step s covers heads 4s..4s+3, a head is selected by
+//    zeroing the other heads' slots of the Q fragment (2 selects per head).
+//  * V is computed in the non-transposed form (tokens in rows): its accumulator registers are the key slots of the A operand
+//    of O^T = V^T.P^T.  Virtual channel 4*head+3 of V is the constant 1 (zero weights, bias 1): row 4*head+3 of O^T is the
+//    softmax denominator, summed by the MFMA from the same f16-rounded P as the numerator.
+//  * The 8 heads of a query block share ONE O^T accumulator: head h's product lands in rows 4h..4h+3, i.e. registers
+//    4(h>>1).. of lane half h&1; 4 selects per head copy them out of the per-head product tile.
+//  * Biases ride on a constant-one k slot (the padding of the 24 -> 32 channel tile), the residual is the C operand of the
+//    projection and fc2 MFMAs: no epilogue arithmetic for either.
+//  * The relative-position bias matrix (variant without shift mask) of the wave's (stream, query block) lives in 32
+//    registers for the whole launch and is the C operand of the S^T MFMAs.  The shift mask (a001:217-315) of the edge windows
+//    is structural in this layout: "last window row" masks whole key tiles, "last window column" masks whole lanes.
+//
+// Arithmetic (SWF_PREC_FAST): linear layers split-bf16 x3 (fp32-grade) on v_mfma_f32_32x32x16_bf16; Q.K^T and P.V on
+// v_mfma_f32_32x32x16_f16 (f16 operands are 8x closer to fp32 than bf16 at the same rate); LayerNorm statistics,
+// softmax, ELU, residual stream, accumulators fp32; exp via v_exp_f32 (Wq, bq and the bias matrix carry log2(e)).
+#include "kernels_win24.h"
+
+#include <algorithm>
+
+namespace swf {
+namespace {
+
+using bf16 = __bf16;
+using f16 = _Float16;
+typedef bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef f16 f16x8 __attribute__((ext_vector_type(8)));
+typedef f16 f16x2 __attribute__((ext_vector_type(2)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
+
+#ifndef W24_FOLD_MAX
+#define W24_FOLD_MAX 1   // S - max on the matrix pipe (second S^T MFMA with -max on the head's spare k slot)
+#endif
+#ifndef W24_MED3
+#define W24_MED3 1       // ELU in exp2 units through one v_med3 (fc1 packed with log2 e, fc2 with ln 2)
+#endif
+#ifndef W24_WAVES
+#define W24_WAVES 3   // resident workgroups per CU = waves per SIMD (register budget 512 / W24_WAVES)
+#endif
+
+// row of accumulator register i in lane half hf (C/D map of the 32x32 MFMAs) == k index of element i & 7 of k-step i >> 3
+__host__ __device__ constexpr int rho(int i, int hf) { return (i & 3) + 8 * (i >> 2) + 4 * hf; }
+
+template <int HID_>
+struct G24 {
+    static constexpr int C = 24, HID = HID_, HEADS = 8, D = 3;
+    static constexpr bool ONES_H = HID % 32 != 0;                 // a spare hidden row carries the constant 1 (fc2 bias slot)
+    static constexpr int NT1 = (HID + (ONES_H ? 1 : 0) + 31) / 32;   // 32-row tiles of fc1
+    static constexpr int KU = (HID + (ONES_H ? 1 : 0) + 15) / 16;    // 16-deep k-steps of fc2
+    // fragment table: every fragment is 64 lanes x 16 bytes (8 bf16), lane-linear
+    static constexpr int F_QKV = 0;                 // [tile q,k,v][k-step 2][hi,lo]
+    static constexpr int F_P = 12;                  // [k-step 2][hi,lo]
+    static constexpr int F_W1 = 16;                 // [tile NT1][k-step 2][hi,lo]
+    static constexpr int F_W2 = F_W1 + 4 * NT1;     // [k-step KU][hi,lo]
+    static constexpr int NFRAG = F_W2 + 2 * KU;
+    static constexpr size_t p_vec = size_t(NFRAG) * 1024;        // fp32 [lane half 2][64]: ln1 g/b, ln2 g/b, b2 (12 each)
+    static constexpr int V_LN1G = 0, V_LN1B = 12, V_LN2G = 24, V_LN2B = 36, V_B2 = 48;
+    static constexpr size_t p_bias = p_vec + 2 * 64 * 4;         // fp32 [query block 2][key tile 2][reg 16][lane 64]
+    static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
+    // LDS (bytes): K images [buf 2][stream 2][key tile 2][k-step 2] x 1 KB, V^T images [buf 2][stream 2][pv-step 4] x 1 KB, vectors
+    static constexpr size_t l_k = 0, l_v = l_k + 16 * 1024, l_vec = l_v + 16 * 1024, l_total = l_vec + 2 * 2 * 64 * 4;
+};
+
+struct Win24Args {
+    const float* in[2];
+    float* out[2];
+    const char* packed[2];
+    const char* warm[2];
+    int B, H, W, shift, cross, warm_bytes;
+};
+
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+__device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+}
+// acc += a . b over one 16-deep k-step with split-bf16 operands (a = a_hi + a_lo, b = b_hi + b_lo): three MFMAs, small cross
+// terms first so they are not absorbed by the large hi.hi partial sums
+__device__ __forceinline__ f32x16 mma3(u32x4 ahi, u32x4 alo, u32x4 bhi, u32x4 blo, f32x16 acc) {
+    acc = mfma_bf16(alo, bhi, acc);
+    acc = mfma_bf16(ahi, blo, acc);
+    acc = mfma_bf16(ahi, bhi, acc);
+    return acc;
+}
+
+// 8 fp32 values -> one k-step fragment in split-bf16 (hi = bf16(v), lo = bf16(v - hi))
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const bf16x2 h = {(bf16)v[2 * p], (bf16)v[2 * p + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        const float h0 = __builtin_bit_cast(float, hu << 16), h1 = __builtin_bit_cast(float, hu & 0xffff0000u);
+        const bf16x2 l = {(bf16)(v[2 * p] - h0), (bf16)(v[2 * p + 1] - h1)};
+        hi[p] = hu;
+        lo[p] = __builtin_bit_cast(unsigned, l);
+    }
+}
+__device__ __forceinline__ u32x4 pack8_f16(const float* v) {
+    u32x4 o;
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const f16x2 h = {(f16)v[2 * p], (f16)v[2 * p + 1]};   // v_cvt_pk_f16_f32 (round to nearest even)
+        o[p] = __builtin_bit_cast(unsigned, h);
+    }
+    return o;
+}
+
+// value of the same register in lane l ^ 32, combined with the own value.  v_permlane32_swap exchanges the upper half of its
+// first operand with the lower half of its second: with both = v, a = [v_lo, v_lo] and b = [v_hi, v_hi] afterwards.
+// (inline asm: hipcc 7.2 folds the builtin's second result into the first; the s_nop covers the VALU-write -> permlane hazard)
+__device__ __forceinline__ void halves(float v, float& a, float& b) {
+    a = v;
+    b = v;
+    asm("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(a), "+v"(b));
+}
+__device__ __forceinline__ float sum_halves(float v) { float a, b; halves(v, a, b); return a + b; }
+__device__ __forceinline__ float max_halves(float v) { float a, b; halves(v, a, b); return __builtin_fmaxf(a, b); }
+
+// The weight fragments are loop-invariant loads: without a fence hipcc hoists them out of the window loop (or to the top of
+// an iteration) and spills.  A compiler-only barrier, no instruction.
+#define W24_FENCE() asm volatile("" ::: "memory")
+
+// A pointer that is the same in every lane of the wave but derived from the wave index: made provably uniform so that hipcc
+// keeps it in SGPRs and addresses fragments as (scalar base + lane offset + immediate) instead of holding a 64-bit per-lane
+// address per fragment group in VGPRs across the window loop.
+template <typename T>
+__device__ __forceinline__ T* uniform_ptr(T* p) {
+    const unsigned long long v = reinterpret_cast<unsigned long long>(p);
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
+}
+
+__device__ __forceinline__ float max3f(float a, float b, float c) { return __builtin_fmaxf(__builtin_fmaxf(a, b), c); }
+
+// LayerNorm (eps 1e-5, biased variance) of the lane's token — 12 of its 24 channels sit in this lane (registers 0..11 of
+// `res`), the other 12 in lane l ^ 32 — straight into the split-bf16 B / A operand fragments of the next linear layer.
+// Slot 12 of lane half 0 (k index rho(12, 0) = 24) is the constant 1 the packed weights keep their bias on.
+__device__ __forceinline__ void layernorm_frags(const f32x16& res, const float* vec, int goff, int boff, u32x4 (&xh)[2], u32x4 (&xl)[2]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) s += res[i];
+    const float mean = sum_halves(s) * (1.0f / 24.0f);
+    float d[12], q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 12; ++i) {
+        d[i] = res[i] - mean;
+        q += d[i] * d[i];
+    }
+    const float rstd = __builtin_amdgcn_rsqf(sum_halves(q) * (1.0f / 24.0f) + 1e-5f);
+    float n[16];
+#pragma unroll
+    for (int a = 0; a < 3; ++a) {
+        const float4 g = *reinterpret_cast<const float4*>(vec + goff + 4 * a);
+        const float4 b = *reinterpret_cast<const float4*>(vec + boff + 4 * a);
+        n[4 * a + 0] = d[4 * a + 0] * rstd * g.x + b.x;
+        n[4 * a + 1] = d[4 * a + 1] * rstd * g.y + b.y;
+        n[4 * a + 2] = d[4 * a + 2] * rstd * g.z + b.z;
+        n[4 * a + 3] = d[4 * a + 3] * rstd * g.w + b.w;
+    }
+    n[12] = 1.0f;   // the bias slot (its weight column is zero in lane half 1)
+    n[13] = n[14] = n[15] = 0.f;
+    split8(n, xh[0], xl[0]);
+    split8(n + 8, xh[1], xl[1]);
+}
+
+// Attention of one wave: 32 queries x 64 keys x 8 heads.  ksrc / vsrc: the stream's K and V^T operand images in LDS (+ lane);
+// qf: the wave's own Q fragments; bias: relative-position bias of (stream, query block), C operand of the S^T MFMAs;
+// m0 / m1 (MASKED only): this lane's scores of key tile 0 / 1 are masked.  Returns the O^T accumulator: registers 4a..4a+3 of
+// lane half p = channels 0..2 and softmax denominator of head 2a + p.
+template <bool MASKED>
+__device__ __forceinline__ f32x16 attention24(const u32x4* ksrc, const u32x4* vsrc, const u32x4 (&qf)[2], const f32x16 (&bias)[2],
+                                              bool half1, bool m0, bool m1) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    f32x16 o = zero16;
+    // Register budget (three, ideally four waves per SIMD): the K / V^T fragments are read from LDS where they are used
+    // instead of being held across the head loop, and a head's P tile is exponentiated, packed and multiplied eight keys at a
+    // time, so that at most the bias (32), the score tile (32, shrinking), the product tile (16) and the output tile (16)
+    // are live together.
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const int s = h >> 2, sub = (h >> 1) & 1;
+        const bool keep = half1 == ((h & 1) != 0);
+        f32x16 s0, s1;
+        {
+            const u32x4 ka0 = ksrc[(0 * 2 + s) * 64], ka1 = ksrc[(1 * 2 + s) * 64];
+            // the head's three channels are elements 4*sub .. 4*sub+2 of lane half h & 1; every other slot is zeroed
+            u32x4 qm = {0u, 0u, 0u, 0u};
+            qm[2 * sub] = keep ? qf[s][2 * sub] : 0u;
+            qm[2 * sub + 1] = keep ? qf[s][2 * sub + 1] : 0u;
+            s0 = mfma_f16(ka0, qm, bias[0]);   // S^T[key][query] + bias, exp2 units
+            s1 = mfma_f16(ka1, qm, bias[1]);
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s0[i] = m0 ? -INFINITY : s0[i];
+                s1[i] = m1 ? -INFINITY : s1[i];
+            }
+        }
+        float mx = max3f(s0[0], s0[1], s1[0]);
+        mx = max3f(mx, s1[1], s0[2]);
+#pragma unroll
+        for (int i = 3; i < 16; i += 2) mx = max3f(mx, s0[i], s0[i + 1 < 16 ? i + 1 : i]);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+        mx = max_halves(mx);   // the other 32 keys of the query sit in lane l ^ 32 (never all masked: a query's own region is not)
+        // S - max on the matrix pipe instead of 32 subtractions on the (saturated) vector pipe: the head's spare k slot (virtual
+        // channel 4h+3) is 1 in every K row and -max (rounded to f16: softmax is shift-invariant, any per-query constant
+        // near the maximum serves) in the Q fragment, and the scores are computed a second time
+        if constexpr (W24_FOLD_MAX) {
+            const u32x4 ka0 = ksrc[(0 * 2 + s) * 64], ka1 = ksrc[(1 * 2 + s) * 64];
+            const f16 nm = (f16)(-mx);
+            const unsigned nmb = keep ? (unsigned)__builtin_bit_cast(unsigned short, nm) : 0u;
+            u32x4 qm = {0u, 0u, 0u, 0u};
+            qm[2 * sub] = keep ? qf[s][2 * sub] : 0u;
+            qm[2 * sub + 1] = (keep ? qf[s][2 * sub + 1] : 0u) | (nmb << 16);
+            s0 = mfma_f16(ka0, qm, bias[0]);
+            s1 = mfma_f16(ka1, qm, bias[1]);
+            if constexpr (MASKED) {
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    s0[i] = m0 ? -INFINITY : s0[i];
+                    s1[i] = m1 ? -INFINITY : s1[i];
+                }
+            }
+        } else {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { s0[i] -= mx; s1[i] -= mx; }
+        }
+        // O^T tile of this head = V^T . P^T over the 64 keys; P = exp2(S - max) in f16, one pv-step (16 keys = registers
+        // 8s'.. of key tile kt) at a time: the exponentials of step ps+1 issue under the MFMA of step ps
+        f32x16 t;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = __builtin_amdgcn_exp2f((ps >> 1) ? s1[8 * (ps & 1) + j] : s0[8 * (ps & 1) + j]);
+            const u32x4 pf = pack8_f16(p);
+            const u32x4 va = vsrc[ps * 64];
+            t = mfma_f16(va, pf, ps == 0 ? zero16 : t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // rows 4h .. 4h+3 (3 channels + denominator) = registers 4(h>>1) .. +3 of lane half h & 1
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[4 * (h >> 1) + j] = keep ? t[4 * (h >> 1) + j] : o[4 * (h >> 1) + j];
+        __builtin_amdgcn_sched_barrier(0);   // one head at a time: interleaving heads doubles the live score tiles
+    }
+    return o;
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+template <int HID>
+__global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args) {
+    using G = G24<HID>;
+    __shared__ __attribute__((aligned(16))) char smem[G::l_total];
+    u32x4* kimg = reinterpret_cast<u32x4*>(smem + G::l_k);   // [buf][stream][key tile][k-step][lane]
+    u32x4* vimg = reinterpret_cast<u32x4*>(smem + G::l_v);   // [buf][stream][pv-step][lane]
+    float* lvec = reinterpret_cast<float*>(smem + G::l_vec);   // [stream][lane half][64]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ws = wave >> 1, qb = wave & 1, r = lane & 31, hf = lane >> 5;
+    const int H = args.H, W = args.W, nwx = W >> 3, nwy = H >> 3, npi = nwx * nwy;
+    const int nwin = args.B * npi;
+    const int sh = args.shift ? 4 : 0;
+    const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
+
+    for (int i = tid; i < 2 * 2 * 64; i += 256) lvec[i] = reinterpret_cast<const float*>(args.packed[i >> 7] + G::p_vec)[i & 127];
+    // Weight fragment f of a stream = 64 lanes x 16 bytes at f * 1024, read through a buffer descriptor: scalar base (made
+    // provably wave-uniform), the lane offset as the 32-bit voffset, the fragment offset as soffset — no address arithmetic on
+    // the VALU and no per-fragment 64-bit address registers (with plain pointers hipcc precomputed one per fragment ahead of
+    // the window loop and spilled 46 registers).  The token rows go the same way.
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
+    const int act_bytes = args.B * H * W * 24 * 4;   // < 2^31 (launch_win24)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(args.in[ws])), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, act_bytes, 0x00020000);
+    const unsigned loff = (unsigned)lane * 16u;
+    auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };   // own stream: Q, proj, MLP
+    auto WK = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, loff, f * 1024, 0)); };   // K / V weights
+    const float* vec = lvec + (ws * 2 + hf) * 64;
+    // relative-position bias of (stream, query block), both key tiles: C operand of the S^T MFMAs for the whole launch
+    f32x16 bias[2];
+    {
+        const float* bm = reinterpret_cast<const float*>(args.packed[ws] + G::p_bias) + qb * 2 * 16 * 64 + lane;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bias[kt][i] = bm[(kt * 16 + i) * 64];
+    }
+    const bool half1 = hf != 0;
+    const bool col_masked = half1 != (((r >> 2) & 1) != 0);   // last-window-column variant: this lane's keys lie across the seam
+    __syncthreads();
+
+    int it = 0;
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x, ++it) {
+        W24_FENCE();
+        const int b = win / npi, wrem = win - b * npi;
+        const int wy = wrem / nwx, wx = wrem - wy * nwx;
+        const int buf = it & 1;
+        // ---- the lane's token: window row 4qb + (r >> 3), column r & 7; cyclic shift = index arithmetic (a001:442-445) ----
+        int oy = wy * 8 + 4 * qb + (r >> 3) + sh, ox = wx * 8 + (r & 7) + sh;
+        oy = oy >= H ? oy - H : oy;
+        ox = ox >= W ? ox - W : ox;
+        const unsigned tokoff = (unsigned)((((b * H + oy) * W + ox) * 24 + 4 * hf) * 4);   // byte offset of the lane's first float4
+        // rows 24..31 of every output tile have zero weights: registers 12..15 stay zero
+        auto load_rows = [&](f32x16& dstv) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                // (one bit_cast of the whole vector: hipcc 7.2 narrows the load to ONE dword and splats it when the four lanes of
+                // the b128 result are bit_cast element by element)
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, tokoff, 32 * a, 0));
+                dstv[4 * a] = v.x; dstv[4 * a + 1] = v.y; dstv[4 * a + 2] = v.z; dstv[4 * a + 3] = v.w;
+            }
+            dstv[12] = dstv[13] = dstv[14] = dstv[15] = 0.f;
+        };
+        const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
+        // ---- LN1, then Q (own stream's weights), K and V (weights of the stream that attends to these tokens) ----
+        u32x4 qf[2];
+        {
+            // the residual rows are NOT kept in registers across the attention phase (16 registers of a 168 budget): they are
+            // read again — an L2 hit, the lines were fetched microseconds ago — as the C operand of the projection
+            f32x16 x0;
+            load_rows(x0);
+            u32x4 xh[2], xl[2];
+            layernorm_frags(x0, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc = mma3(WF(G::F_QKV + 2 * s), WF(G::F_QKV + 2 * s + 1), xh[s], xl[s], acc);
+            float t[16];
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = acc[i];
+            qf[0] = pack8_f16(t);
+            qf[1] = pack8_f16(t + 8);
+            W24_FENCE();
+            acc = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc = mma3(WK(G::F_QKV + 4 + 2 * s), WK(G::F_QKV + 5 + 2 * s), xh[s], xl[s], acc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = acc[i];
+            u32x4* kdst = kimg + (((buf * 2 + kvs) * 2 + qb) * 2) * 64 + lane;
+            kdst[0] = pack8_f16(t);
+            kdst[64] = pack8_f16(t + 8);
+            W24_FENCE();
+            // V: tokens in rows (A = x fragments, B = weight fragments): register i of lane (channel r, hf) is token rho(i, hf)
+            acc = zero16;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc = mma3(xh[s], xl[s], WK(G::F_QKV + 8 + 2 * s), WK(G::F_QKV + 9 + 2 * s), acc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) t[i] = acc[i];
+            u32x4* vdst = vimg + ((buf * 2 + kvs) * 4 + 2 * qb) * 64 + lane;
+            vdst[0] = pack8_f16(t);
+            vdst[64] = pack8_f16(t + 8);
+        }
+        __syncthreads();   // K / V^T images of both streams complete (the buffers of the window before stay readable)
+
+        // ---- attention of the wave's 32 queries, 8 heads ----
+        // Shift mask (a001:217-315; the reference ASSIGNS -1e10 to the masked scores, so their probabilities are exactly 0):
+        // only the windows of the last window row / column of a shifted block hold two region labels, split at row /
+        // column 4 of the window.  In the S^T layout "query and key on different sides of the row seam" is a whole key tile
+        // (key tile kt holds window rows 4kt..4kt+3, the wave's queries rows 4qb..4qb+3) and "different sides of the column
+        // seam" is a whole lane (lane half hf holds key columns 4hf..4hf+3, the lane's query column is r & 7).  The masked
+        // variant is a separate instantiation: a wave-uniform branch around it instead of branches inside the head loop
+        // (those cost 60 registers of live-range extension).
+        f32x16 o;
+        {
+            const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
+            const u32x4* ksrc = kimg + ((buf * 2 + ws) * 4) * 64 + lane;
+            const u32x4* vsrc = vimg + ((buf * 2 + ws) * 4) * 64 + lane;
+            if (rowv || colv) {
+                const bool m0 = (rowv && qb == 1) || (colv && col_masked), m1 = (rowv && qb == 0) || (colv && col_masked);
+                o = attention24<true>(ksrc, vsrc, qf, bias, half1, m0, m1);
+            } else {
+                o = attention24<false>(ksrc, vsrc, qf, bias, half1, false, false);
+            }
+        }
+
+        // ---- normalise, output projection + bias + residual: res is the C operand ----
+        f32x16 res;
+        W24_FENCE();
+        load_rows(res);
+        {
+            float t[16];
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const float inv = __builtin_amdgcn_rcpf(o[4 * a + 3]);
+                t[4 * a] = o[4 * a] * inv; t[4 * a + 1] = o[4 * a + 1] * inv; t[4 * a + 2] = o[4 * a + 2] * inv;
+                t[4 * a + 3] = 1.0f;   // slot rho = 4*head + 3: constant one (the projection bias sits on head 0's)
+            }
+            u32x4 oh[2], ol[2];
+            split8(t, oh[0], ol[0]);
+            split8(t + 8, oh[1], ol[1]);
+            W24_FENCE();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) res = mma3(WF(G::F_P + 2 * s), WF(G::F_P + 2 * s + 1), oh[s], ol[s], res);
+        }
+
+        // ---- LN2, MLP: fc1 tile -> ELU -> split -> two k-steps of fc2 accumulating onto the residual ----
+        {
+            u32x4 xh[2], xl[2];
+            layernorm_frags(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+#pragma unroll
+            for (int tI = 0; tI < G::NT1; ++tI) {
+                W24_FENCE();
+                f32x16 acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    acc = mma3(WF(G::F_W1 + 4 * tI + 2 * s), WF(G::F_W1 + 4 * tI + 2 * s + 1), xh[s], xl[s], acc);
+                // ELU(alpha = 1) in exp2 units: the packed fc1 weights carry log2(e) (acc = u = v log2 e) and the packed fc2
+                // weights ln 2, so the kernel needs h' = ELU(v) log2(e) = u for u > 0, L = log2(e) (2^u - 1) otherwise.  u <= L
+                // everywhere (convexity) and L <= 0 exactly when u <= 0, so h' is the median of (u, L, 0): 3 instructions per
+                // hidden activation (exp, fma, med3) instead of multiply, exp, add, compare, select.
+                float e[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) {
+                    const float u = acc[i];
+                    if constexpr (W24_MED3) {
+                        const float L = __builtin_fmaf(__builtin_amdgcn_exp2f(u), kLog2e, -kLog2e);
+                        e[i] = __builtin_amdgcn_fmed3f(u, L, 0.f);
+                    } else {
+                        e[i] = u > 0.f ? u : __builtin_amdgcn_exp2f(u * kLog2e) - 1.0f;
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    const int u = 2 * tI + s2;
+                    if (u < G::KU) {
+                        u32x4 hh, hl;
+                        split8(e + 8 * s2, hh, hl);
+                        W24_FENCE();
+                        res = mma3(WF(G::F_W2 + 2 * u), WF(G::F_W2 + 2 * u + 1), hh, hl, res);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one hidden tile at a time
+            }
+            if constexpr (!G::ONES_H) {   // no spare hidden row to carry the fc2 bias
+#pragma unroll
+                for (int a = 0; a < 3; ++a) {
+                    const float4 b2 = *reinterpret_cast<const float4*>(vec + G::V_B2 + 4 * a);
+                    res[4 * a] += b2.x; res[4 * a + 1] += b2.y; res[4 * a + 2] += b2.z; res[4 * a + 3] += b2.w;
+                }
+            }
+        }
+
+        // ---- store the own rows (un-shift = the same index map) ----
+#pragma unroll
+        for (int a = 0; a < 3; ++a) {
+            const f32x4 v = {res[4 * a], res[4 * a + 1], res[4 * a + 2], res[4 * a + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, tokoff, 32 * a, 0);
+        }
+    }
+
+    // ---- L2 warm-up of the next block's packed weights (cold since the previous forward; see kernels_window.hip) ----
+    if (args.warm[0]) {
+        const int nsl = max(1, (int)gridDim.x / 8), sl = ((int)blockIdx.x / 8) % nsl;
+        const int lines = (args.warm_bytes + 127) / 128;
+        const int per = (lines + nsl - 1) / nsl, l0 = sl * per, l1 = min(lines, l0 + per);
+        unsigned acc = 0;
+        for (int s2 = 0; s2 < 2; ++s2)
+            for (int l = l0 + tid; l < l1; l += 256) acc ^= *reinterpret_cast<const unsigned*>(args.warm[s2] + (size_t)l * 128);
+        if (acc == 0x9e3779b9u && args.B < 0) args.out[0][0] = 0.f;   // never true: keeps the loads alive
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+// weight packing: fp32 nn.Parameter tensors -> fragment-major split-bf16 images with their k columns in rho order
+// ---------------------------------------------------------------------------------------------------------------
+struct Pack24Args {
+    swf_block_stream_params p[2];
+    char* dst[2];
+};
+
+template <int HID>
+__global__ __launch_bounds__(256) void pack24_kernel(Pack24Args a) {
+    using G = G24<HID>;
+    const int s = blockIdx.y;
+    const swf_block_stream_params& p = a.p[s];
+    char* dst = a.dst[s];
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    const float qscale = kLog2e / sqrtf(3.0f);   // d^-0.5 (a001:32-34) and exp -> exp2
+    auto lin = [](const swf_linear& l, int n, int k, int ld) { return l.weight[n * ld + k]; };
+    auto bia = [](const swf_linear& l, int n) { return l.bias ? l.bias[n] : 0.f; };
+
+    for (int idx = gtid; idx < G::NFRAG * 512; idx += gsz) {
+        const int f = idx >> 9, lane = (idx >> 3) & 63, e = idx & 7;
+        const int r = lane & 31, hf = lane >> 5;
+        float val = 0.f;
+        int hl;
+        if (f < G::F_P) {   // Q / K / V: row (A) or column (B) r = virtual channel 4*head + c; k = input channel in rho order, slot 24 = bias
+            const int t = f >> 2, st = (f >> 1) & 1;
+            hl = f & 1;
+            const int k = rho(8 * st + e, hf), head = r >> 2, c = r & 3;
+            const swf_linear& l = t == 0 ? p.attn.q : t == 1 ? p.attn.k : p.attn.v;
+            if (c < 3) {
+                const int row = 3 * head + c;
+                val = k < 24 ? lin(l, row, k, 24) : (k == 24 ? bia(l, row) : 0.f);
+                if (t == 0) val *= qscale;
+            } else if (t != 0 && k == 24) {
+                // virtual channel 4*head+3: the constant 1 (zero weights, bias 1).  V: its O^T row is the softmax denominator.
+                // K: the k slot on which the Q fragment carries -max (attention24).  Q: stays zero.
+                val = 1.0f;
+            }
+        } else if (f < G::F_W1) {   // projection: row r = output channel; k = virtual channel 4*head + c of O, slot 3 = bias
+            const int st = ((f - G::F_P) >> 1) & 1;
+            hl = f & 1;
+            const int k = rho(8 * st + e, hf), head = k >> 2, c = k & 3;
+            if (r < 24) val = c < 3 ? lin(p.attn.proj, r, 3 * head + c, 24) : (k == 3 ? bia(p.attn.proj, r) : 0.f);
+        } else if (f < G::F_W2) {   // fc1: row = hidden unit; k = input channel in rho order, slot 24 = bias
+            const int g = f - G::F_W1, t = g >> 2, st = (g >> 1) & 1;
+            hl = g & 1;
+            const int k = rho(8 * st + e, hf), hid = 32 * t + r;
+            if (hid < HID) val = (k < 24 ? lin(p.fc1, hid, k, 24) : (k == 24 ? bia(p.fc1, hid) : 0.f)) * (W24_MED3 ? kLog2e : 1.0f);   // exp2 units (ELU in the kernel)
+            else if (G::ONES_H && hid == HID && k == 24) val = 1.0f;   // u = 1 -> h' = 1: the constant the fc2 bias rides on
+        } else {   // fc2: row r = output channel; k-step u covers hidden units 32(u>>1) + rho(8(u&1) + e, hf)
+            const int g = f - G::F_W2, u = g >> 1;
+            hl = g & 1;
+            const int hid = 32 * (u >> 1) + rho(8 * (u & 1) + e, hf);
+            if (r < 24) val = hid < HID ? lin(p.fc2, r, hid, HID) * (W24_MED3 ? kLn2 : 1.0f) : ((G::ONES_H && hid == HID) ? bia(p.fc2, r) : 0.f);   // h' = ELU log2(e)
+        }
+        const bf16 hi = (bf16)val;
+        reinterpret_cast<bf16*>(dst)[idx] = hl ? (bf16)(val - (float)hi) : hi;
+    }
+    float* vec = reinterpret_cast<float*>(dst + G::p_vec);
+    for (int i = gtid; i < 128; i += gsz) {
+        const int hf = i >> 6, j = i & 63, which = j / 12, k = j % 12;
+        const int c = 8 * (k >> 2) + 4 * hf + (k & 3);
+        float v = 0.f;
+        if (which == 0) v = p.ln1.gamma[c];
+        else if (which == 1) v = p.ln1.beta[c];
+        else if (which == 2) v = p.ln2.gamma[c];
+        else if (which == 3) v = p.ln2.beta[c];
+        else if (which == 4) v = p.fc2.bias ? p.fc2.bias[c] : 0.f;
+        vec[i] = v;
+    }
+    // relative-position bias (a001:113-144), exp2 units, in S^T accumulator order: [query block][key tile][register][lane]
+    float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
+        const int lane = i & 63, reg = (i >> 6) & 15, kt = (i >> 10) & 1, qb = i >> 11;
+        const int key = 32 * kt + rho(reg, lane >> 5), q = 32 * qb + (lane & 31);
+        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7;
+        bm[i] = p.attn.bias_table[(ky - qy + 7) * 15 + (kx - qx + 7)] * kLog2e;
+    }
+}
+
+int num_cus24() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+}  // namespace
+
+bool win24_supported(const swf_block_desc& d) {
+    return d.attn.channels == 24 && d.attn.heads == 8 && d.attn.head_dim == 3 && d.attn.win_h == 8 && d.attn.win_w == 8 &&
+           (d.hidden == 96 || d.hidden == 4);
+}
+
+size_t win24_packed_bytes(const swf_block_desc& d) {
+    if (!win24_supported(d)) return 0;
+    return align_up(d.hidden == 96 ? G24<96>::p_total : G24<4>::p_total, 256);
+}
+
+int pack_win24(const swf_block_desc& d, const swf_block_stream_params& px, const swf_block_stream_params& py, void* packed_x,
+               void* packed_y, hipStream_t stream) {
+    if (!win24_supported(d)) return fail(SWF_ERR_UNSUPPORTED, "pack_win24: shape not covered");
+    Pack24Args a;
+    a.p[0] = px; a.p[1] = py;
+    a.dst[0] = static_cast<char*>(packed_x); a.dst[1] = static_cast<char*>(packed_y);
+    if (d.hidden == 96) hipLaunchKernelGGL((pack24_kernel<96>), dim3(32, 2), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((pack24_kernel<4>), dim3(32, 2), dim3(256), 0, stream, a);
+    return check_launch("pack_win24");
+}
+
+int launch_win24(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,
+                 float* x_out, float* y_out, int B, int H, int W, hipStream_t stream, const void* next_packed_x,
+                 const void* next_packed_y, size_t next_bytes) {
+    if (!win24_supported(d) || H % 8 || W % 8) return fail(SWF_ERR_UNSUPPORTED, "win24: shape not covered");
+    if ((int64_t)B * H * W * 24 * 4 >= (int64_t(1) << 31)) return fail(SWF_ERR_UNSUPPORTED, "win24: a stream of %d x %d x %d tokens exceeds the 2 GB buffer window", B, H, W);
+    Win24Args a;
+    a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
+    a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
+    a.warm[0] = static_cast<const char*>(next_packed_x); a.warm[1] = static_cast<const char*>(next_packed_y);
+    if (!a.warm[1]) a.warm[0] = nullptr;
+    a.warm_bytes = (int)(next_bytes ? next_bytes : win24_packed_bytes(d));
+    a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
+    const int nwin = B * (H / 8) * (W / 8);
+    const int grid = std::min(nwin, W24_WAVES * num_cus24());   // resident workgroups per CU (register-limited)
+    if (d.hidden == 96) hipLaunchKernelGGL((window24_kernel<96>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((window24_kernel<4>), dim3(grid), dim3(256), 0, stream, a);
+    return check_launch("window24");
+}
+
+}  // namespace swf

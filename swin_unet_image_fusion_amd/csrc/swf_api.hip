@@ -679,7 +679,9 @@ static swf_block_desc level_block_desc(const swf_model_desc* d, int lvl, bool en
 static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                             const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
                             void* workspace, size_t workspace_bytes, hipStream_t stream, const char* packed = nullptr,
-                            const char* after = nullptr, size_t after_pb = 0) {
+                            const char* after = nullptr, size_t after_pb = 0, int32_t* equal_flags = nullptr) {
+    // `equal_flags` (device, 2 entries pre-set to 1, or nullptr): cleared when the inputs of the stage's two cross blocks
+    // differ somewhere — the reference's first-forward check `(x == y).all()` (a005:111-118)
     // `after`: packed images (x, then y at + after_pb) of the first block of the NEXT stage when that is a fused-kernel stage
     // too: the last block of this stage warms them
     const float* xi = x_in;
@@ -695,6 +697,8 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
         const void* nkx = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 2) * pb : (i == 3 ? after : nullptr);   // next block: warmed in L2
         const void* nky = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 3) * pb : (i == 3 && after ? after + after_pb : nullptr);
         const swf_block_stream_params* nxt[2] = {i < 3 ? &px[i + 1] : nullptr, (i < 3 && py) ? &py[i + 1] : nullptr};
+        if (equal_flags && d.cross && py)
+            SWF_TRY(launch_all_equal(xi, yi, (int64_t)B * H * W * desc->attn.channels, equal_flags + (i - 2), stream));
         SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream, pkx, pky,
                                  nkx, nky, i == 3 ? after_pb : 0, i < 3 ? nxt : nullptr, &ln1_ready));
         xi = x_out; yi = y_out;
@@ -1011,7 +1015,8 @@ int swf_model_pack_weights(const swf_model_desc* desc, const float* arena, void*
 }
 
 static int model_forward_impl(const swf_model_desc* desc, const float* arena, const char* packed, const float* ir, const float* vis, float* out,
-                              int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream_) {
+                              int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream_,
+                              int32_t* equal_flags = nullptr) {
     SWF_TRY(check_model_desc(desc));
     const PackedPlan plan = packed_plan(desc);
     if (!arena || !ir || !vis || !out) return fail(SWF_ERR_NULL, "model_forward: NULL tensor");
@@ -1052,7 +1057,8 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
             if (window_block_packed_bytes(nb) && plan.enc_on[s + 1]) { after = packed + plan.enc[s + 1]; after_pb = window_block_packed_bytes(nb); }
         }
         SWF_TRY(block_pair4_impl(&bd, px, py, act[s][0], act[s][1], act[s][0], act[s][1], B, ls[s].Ho, ls[s].Wo, scratch, scratch_bytes, stream,
-                                 (packed && plan.enc_on[s]) ? packed + plan.enc[s] : nullptr, after, after_pb));
+                                 (packed && plan.enc_on[s]) ? packed + plan.enc[s] : nullptr, after, after_pb,
+                                 equal_flags ? equal_flags + 2 * s : nullptr));
         cur[0] = act[s][0]; cur[1] = act[s][1];
     }
     // decoder (a013:221-227): the skip add of stage j+1 is folded into stage j's unmerge epilogue,
@@ -1069,7 +1075,8 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
             if (window_block_packed_bytes(nb) && plan.dec_on[j + 1]) { after = packed + plan.dec[j + 1]; after_pb = window_block_packed_bytes(nb); }
         }
         SWF_TRY(block_pair4_impl(&bd, px, py, act[lvl][0], act[lvl][1], act[lvl][0], act[lvl][1], B, ls[lvl].Ho, ls[lvl].Wo, scratch, scratch_bytes, stream,
-                                 (packed && plan.dec_on[j]) ? packed + plan.dec[j] : nullptr, after, after_pb));
+                                 (packed && plan.dec_on[j]) ? packed + plan.dec[j] : nullptr, after, after_pb,
+                                 equal_flags ? equal_flags + 2 * (n + j) : nullptr));
         // a deep-level stage cannot warm its successor from inside a block kernel: one small launch does it
         if (after && window_block_packed_bytes(bd) == 0) SWF_TRY(launch_l2_warm(after, 2 * after_pb, stream));
         swf_patch_params pm[2] = {patch_params(L->dec_patch[j][0]), patch_params(L->dec_patch[j][1])};
@@ -1095,6 +1102,24 @@ int swf_model_forward(const swf_model_desc* desc, const float* arena, const floa
 int swf_model_forward_packed(const swf_model_desc* desc, const float* arena, const void* packed, const float* ir, const float* vis,
                              float* out, int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream) {
     return model_forward_impl(desc, arena, static_cast<const char*>(packed), ir, vis, out, B, H, W, workspace, workspace_bytes, stream);
+}
+
+int swf_model_forward_checked(const swf_model_desc* desc, const float* arena, const void* packed, const float* ir, const float* vis,
+                              float* out, int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes,
+                              int32_t* cross_equal_flags, swf_stream_t stream) {
+    if (!cross_equal_flags) return fail(SWF_ERR_NULL, "model_forward_checked: NULL flags");
+    if (check_model_desc(desc) != SWF_OK) return SWF_ERR_BAD_SHAPE;
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(cross_equal_flags), 1, (size_t)4 * desc->levels, as_stream(stream));
+    if (e != hipSuccess) return fail(SWF_ERR_HIP, "model_forward_checked: memset: %s", hipGetErrorString(e));
+    return model_forward_impl(desc, arena, static_cast<const char*>(packed), ir, vis, out, B, H, W, workspace, workspace_bytes, stream,
+                              cross_equal_flags);
+}
+
+int swf_tensors_equal(const float* a, const float* b, int64_t count, int32_t* flag, swf_stream_t stream) {
+    if (!flag) return fail(SWF_ERR_NULL, "tensors_equal: NULL flag");
+    hipError_t e = hipMemsetD32Async(reinterpret_cast<hipDeviceptr_t>(flag), 1, 1, as_stream(stream));
+    if (e != hipSuccess) return fail(SWF_ERR_HIP, "tensors_equal: memset: %s", hipGetErrorString(e));
+    return launch_all_equal(a, b, count, flag, as_stream(stream));
 }
 
 }  // extern "C"

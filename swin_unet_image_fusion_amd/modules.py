@@ -39,7 +39,26 @@ def _ptr(t: Optional[Tensor]) -> Optional[int]:
     return t.data_ptr()
 
 
+_BOUND_DEVICE: Optional[int] = None
+
+
 def _stream(device) -> int:
+    """Current HIP stream of `device`.  libswinfuse launches on the calling thread's current HIP device and caches
+    per-device facts (CU count, kernel attributes) once per process, so a process is bound to ONE GPU — the deployment
+    model of this package (one process per GPU, shard.py).  A second device, or a current device that differs from the
+    tensors' device, raises instead of launching on the wrong GPU."""
+    global _BOUND_DEVICE
+    idx = torch.device(device).index
+    if idx is None:
+        idx = torch.cuda.current_device()
+    if _BOUND_DEVICE is None:
+        _BOUND_DEVICE = idx
+    if idx != _BOUND_DEVICE:
+        raise RuntimeError(f"libswinfuse is bound to cuda:{_BOUND_DEVICE} in this process (one process per GPU); "
+                           f"got a tensor on cuda:{idx}")
+    if torch.cuda.current_device() != idx:
+        raise RuntimeError(f"tensors live on cuda:{idx} but the current device is cuda:{torch.cuda.current_device()}; "
+                           "call torch.cuda.set_device() first (the library launches on the current HIP device)")
     return torch.cuda.current_stream(device).cuda_stream
 
 
@@ -629,6 +648,11 @@ class MyModel(_FwdAlias, nn.Module):
         self._arena: Optional[Tensor] = None
         self._arena_key = None
         self._packed: Optional[Tensor] = None
+        # bumped whenever the arena / packed images are dropped: anything that baked their addresses into a captured
+        # hipGraph (shard.ShardedFusion) compares it before replaying
+        self.weights_epoch = 0
+        # the reference's first-forward input check (a005:98-118), None = not run yet
+        self.input_compatibility_with_cross_option: Optional[bool] = None
 
         enc, dec = deque(), deque()
         for j in range(len(self.in_dims_list) - 1, -1, -1):   # a013:154-207
@@ -676,10 +700,18 @@ class MyModel(_FwdAlias, nn.Module):
         Called automatically after load_state_dict() and .to(); call it by hand after editing
         parameters in place."""
         self._arena, self._arena_key, self._packed = None, None, None
+        self.weights_epoch += 1
 
     def _apply(self, fn, *a, **kw):
         self._arena, self._arena_key, self._packed = None, None, None
+        self.weights_epoch = getattr(self, "weights_epoch", 0) + 1
         return super()._apply(fn, *a, **kw)
+
+    def graph_key(self):
+        """Everything a captured forward depends on besides the input shape: the weights epoch, the arithmetic mode and
+        the addresses of the arena / packed images (None before the first forward)."""
+        return (self.weights_epoch, self.precision, None if self._arena is None else self._arena.data_ptr(),
+                None if self._packed is None else self._packed.data_ptr())
 
     def param_layout(self):
         """[(state_dict key, element offset, numel)] of the arena, as defined by the library."""
@@ -703,15 +735,24 @@ class MyModel(_FwdAlias, nn.Module):
             total = lib.swf_model_arena_elems(C.byref(desc))
             sd = self.state_dict()
             layout = self.param_layout()
-            host = torch.zeros(total, dtype=torch.float32)
+            # packed on the device: the parameters (already there after .to()) are concatenated in layout order with the
+            # library's 16-byte alignment gaps — a handful of concat kernels instead of one host round trip per tensor
+            pieces, pos = [], 0
             for name, off, num in layout:
                 t = sd[name]
                 if t.numel() != num:
                     raise RuntimeError(f"{name}: expected {num} elements, got {t.numel()}")
-                host[off:off + num] = t.detach().reshape(-1).to("cpu", torch.float32)
-            self._arena = host.to(device)
+                if off > pos:
+                    pieces.append(torch.zeros(off - pos, dtype=torch.float32, device=device))
+                pieces.append(t.detach().reshape(-1).to(device=device, dtype=torch.float32))
+                pos = off + num
+            if total > pos:
+                pieces.append(torch.zeros(total - pos, dtype=torch.float32, device=device))
+            self._arena = torch.cat(pieces)
+            assert self._arena.numel() == total
             self._arena_key = key
             self._packed = None
+            self.weights_epoch += 1
         return self._arena
 
     def _get_packed(self, arena: Tensor) -> Optional[Tensor]:
@@ -750,8 +791,25 @@ class MyModel(_FwdAlias, nn.Module):
         lib, desc = L.lib(), self._model_desc()
         need = lib.swf_model_workspace_bytes(C.byref(desc), b, h, w)
         ws, wsn = _workspace(need, x.device)
+        packed = self._get_packed(arena) if desc.precision == L.PREC_FAST else None
+        if self.input_compatibility_with_cross_option is None:
+            # First forward: the reference checks, in front of every cross-attention block, that its two input streams
+            # are not identical everywhere, and otherwise prints and calls exit() (a005:98-118).  The library records
+            # the same test per cross block on the device; here it raises ValueError (documented deviation).
+            flags = torch.ones(4 * len(self.in_dims_list), dtype=torch.int32, device=x.device)
+            L.check(lib.swf_model_forward_checked(C.byref(desc), _ptr(arena), packed.data_ptr() if packed is not None else None,
+                                                  _ptr(x), _ptr(y), _ptr(out), b, h, w, ws, wsn, flags.data_ptr(),
+                                                  _stream(x.device)))
+            same = flags.cpu().nonzero().flatten().tolist()
+            if same:
+                self.input_compatibility_with_cross_option = False
+                n = len(self.in_dims_list)
+                where = [f"{'encoder' if i // 2 < n else 'decoder'}_list.{(i // 2) % n} cross block {i % 2}" for i in same]
+                raise ValueError("inputs are incompatible with the cross_attr option: cross attention received identical "
+                                 f"x and y ({', '.join(where)}); the reference calls exit() here (a005:111-118)")
+            self.input_compatibility_with_cross_option = True
+            return out
         if desc.precision == L.PREC_FAST:
-            packed = self._get_packed(arena)
             L.check(lib.swf_model_forward_packed(C.byref(desc), _ptr(arena), packed.data_ptr(), _ptr(x), _ptr(y), _ptr(out),
                                                  b, h, w, ws, wsn, _stream(x.device)))
         else:

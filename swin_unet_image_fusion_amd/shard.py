@@ -30,8 +30,16 @@ class ShardedFusion:
     """step(ir, vis): run this rank's pairs and return the fused output of ALL ranks, rank-major.
 
     forward_fn defaults to `model(ir, vis)` (the HIP path).  With `use_graph` the forward is captured
-    once per input shape into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed: ~300 kernel
-    launches per forward collapse into one graph launch.  The collective stays outside the graph."""
+    into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed: ~100 kernel launches per forward
+    collapse into one graph launch.  The collective stays outside the graph.
+
+    A captured graph bakes in raw addresses: the model's weight arena and packed images, the library
+    workspace, the arithmetic mode and the static input / output buffers.  It is therefore keyed on
+    (input shape, model.graph_key()) and re-captured whenever either changes — after load_state_dict(),
+    refresh_weights(), .to() or `model.precision = ...` the next step runs the new weights (a017:50-54: load,
+    then infer).  The static input buffers belong to the runner (callers' tensors are copied in, never
+    adopted), and the tensor returned by local_forward()/step() at world_size 1 is the runner's static
+    output buffer: it is overwritten by the next step — clone it to keep it."""
 
     def __init__(self, model=None, world_size: int = 1, rank: int = 0, use_graph: bool = False,
                  forward_fn: Optional[Callable] = None, group=None):
@@ -41,14 +49,24 @@ class ShardedFusion:
         self.graph_active = False
         self._graph = None
         self._static = None   # (ir, vis, out) of the captured graph
+        self._key = None      # (input shape, model.graph_key()) the graph was captured for
         self._gathered = None
+        self._cap_stream = None   # one capture stream for the runner's lifetime: the library workspace is keyed by stream
+        self.captures = 0
 
     # -- forward of the local shard --------------------------------------------------------------
+    def _model_key(self):
+        return self.model.graph_key() if hasattr(self.model, "graph_key") else None
+
     def _capture(self, ir, vis):
-        self.forward_fn(ir, vis)                      # warm-up: sizes the workspace, builds the arena
+        ir, vis = ir.clone(), vis.clone()             # runner-owned static buffers
+        self._graph = self._static = None             # drop the old graph before its buffers
+        self.forward_fn(ir, vis)                      # warm-up: sizes the workspace, builds the arena, first-forward check
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        s = torch.cuda.Stream(device=ir.device)
+        if self._cap_stream is None:
+            self._cap_stream = torch.cuda.Stream(device=ir.device)
+        s = self._cap_stream
         s.wait_stream(torch.cuda.current_stream(ir.device))
         with torch.cuda.stream(s):
             self.forward_fn(ir, vis)                  # warm-up on the capture stream (its own workspace)
@@ -57,17 +75,17 @@ class ShardedFusion:
                 out = self.forward_fn(ir, vis)
         torch.cuda.current_stream(ir.device).wait_stream(s)
         self._graph, self._static, self.graph_active = g, (ir, vis, out), True
+        self._key = (tuple(ir.shape), self._model_key())   # after the capture: the arena / packed images exist now
+        self.captures += 1
 
     def local_forward(self, ir, vis):
         if not (self.use_graph and ir.is_cuda):
             return self.forward_fn(ir, vis)
-        if self._static is None or self._static[0].shape != ir.shape:
+        if self._static is None or self._key != (tuple(ir.shape), self._model_key()):
             self._capture(ir, vis)
         s_ir, s_vis, s_out = self._static
-        if s_ir.data_ptr() != ir.data_ptr():
-            s_ir.copy_(ir)
-        if s_vis.data_ptr() != vis.data_ptr():
-            s_vis.copy_(vis)
+        s_ir.copy_(ir)
+        s_vis.copy_(vis)
         self._graph.replay()
         return s_out
 

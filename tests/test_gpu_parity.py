@@ -10,15 +10,20 @@ from torch import nn
 import __graft_entry__ as entry
 from oracle import swin_fusion_oracle as O
 from swin_unet_image_fusion_amd import (CONFIGS, AddAndLayerNormWithOtherModule, AutoPathMLP, AutoPathWinAtt, BasicBlock,
-                                        MyModel, MyPadding, PatchMergingAndLinearLayer, SelfAndCrossBlockPair,
-                                        StateRecorder, WindowAttention, load_recipe_into, synthetic_pair)
+                                        MyModel, MyPadding, NormalAndShiftWinsBlockPair, PatchMergingAndLinearLayer,
+                                        SelfAndCrossBlockPair, StateRecorder, WindowAttention, load_recipe_into, synthetic_pair)
+from swin_unet_image_fusion_amd.shard import ShardedFusion
 from tests import golden_util as G
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 TOL_FP32 = 2e-5
 TOL_FAST_L2 = 1e-3
-TOL_FAST_MAX = 5e-3
+# max|err| / max|ref|: the same 1e-3 as the rel-L2 bar (north star: "within 1e-3 relative").  Measured on MI355X
+# (profiles/r02_parity.json): whole-model fixtures <= 4e-4, single blocks with stress weights <= 6e-4.
+TOL_FAST_MAX = 1e-3
+
+_PARITY_LOG = []   # (test id, rel-L2, max-rel): dumped to gpurun_out/parity.json at the end of the module
 
 
 @pytest.fixture(scope="module", autouse=True)
@@ -27,6 +32,28 @@ def _built():
     torch.set_grad_enabled(False)
     yield
     torch.set_grad_enabled(True)
+    # per-fixture parity numbers of this run (copied into profiles/ by hand when they are to be judged)
+    import json, os
+    out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
+    try:
+        os.makedirs(out_dir, exist_ok=True)
+        with open(os.path.join(out_dir, "parity.json"), "w") as f:
+            json.dump({"metric": "rel-L2 = |out-ref|_2/|ref|_2, max-rel = max|out-ref|/max|ref|; ref = golden vector captured from the "
+                                 "reference (or the CPU oracle where the test says so)",
+                       "gates": {"fp32": TOL_FP32, "fp32_model": 5e-5, "fast_rel_l2": TOL_FAST_L2, "fast_max_rel": TOL_FAST_MAX},
+                       "records": [{"test": t, "rel_l2": a, "max_rel": b} for t, a, b in _PARITY_LOG]}, f, indent=1)
+    except OSError:
+        pass
+
+
+@pytest.fixture(autouse=True)
+def _test_id(request):
+    global _CUR_TEST
+    _CUR_TEST = request.node.name
+    yield
+
+
+_CUR_TEST = ""
 
 
 def _close(got, exp, tol=TOL_FP32, tol_max=None):
@@ -34,6 +61,7 @@ def _close(got, exp, tol=TOL_FP32, tol_max=None):
     assert got.shape == exp.shape, (got.shape, exp.shape)
     assert torch.isfinite(got).all()
     l2, mx = G.rel_err(got, exp)
+    _PARITY_LOG.append((_CUR_TEST, l2, mx))
     assert l2 <= tol and mx <= (tol_max or tol), (l2, mx)
     return l2, mx
 
@@ -83,6 +111,24 @@ def test_self_and_cross_block_pair(name, precision):
     tol, tmax = (TOL_FP32, None) if precision == "fp32" else (TOL_FAST_L2, TOL_FAST_MAX)
     _close(ox, arr["expected_x"], tol, tmax)
     _close(oy, arr["expected_y"], tol, tmax)
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+@pytest.mark.parametrize("name", G.cases("normal_and_shift_block_pair"))
+def test_normal_and_shift_block_pair(name, precision):
+    """NormalAndShiftWinsBlockPair.forward (a009:90-109) called directly: plain-window block, then shifted-window block."""
+    meta, arr = G.load(name)
+    m = NormalAndShiftWinsBlockPair(**meta["ctor"], mlp_activation_func=_elu()).eval()
+    load_recipe_into(m, seed=meta["weight_seed"], flavor=meta["flavor"])
+    m.to(DEV)
+    m.normal_window_block.precision = m.shifted_window_block.precision = precision
+    x, y = G.randn(meta["in_shape"], meta["seed_x"]).to(DEV), G.randn(meta["in_shape"], meta["seed_y"]).to(DEV)
+    ox, oy = m(x, y)
+    tol, tmax = (TOL_FP32, None) if precision == "fp32" else (TOL_FAST_L2, TOL_FAST_MAX)
+    _close(ox, arr["expected_x"], tol, tmax)
+    _close(oy, arr["expected_y"], tol, tmax)
+    fx, fy = m.forward_(x, y)
+    assert torch.equal(fx, ox) and torch.equal(fy, oy)
 
 
 def test_inner_modules_compose_like_the_block():
@@ -195,6 +241,133 @@ def test_full_size_batch_properties(precision):
     assert torch.equal(torch.cat([lo, hi]), out)
     one = m(ir[5:6].contiguous(), vis[5:6].contiguous())
     assert torch.equal(one, out[5:6])
+
+
+def _full_size_properties(cfg_name, golden, batch, size, precision):
+    """finite; sample 0 == the B=1 golden vector of the reference; repeat == repeat; batch shards == rows of the full batch"""
+    meta, arr = G.load(golden)
+    cfg = CONFIGS[cfg_name]
+    m = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(m, seed=0, flavor="default")
+    m.to(DEV)
+    m.precision = precision
+    ir, vis = (torch.from_numpy(a).to(DEV) for a in synthetic_pair(batch, size, size))
+    out = m(ir, vis)
+    assert out.shape == (batch, 1, size, size) and torch.isfinite(out).all()
+    tol = (5e-5, None) if precision == "fp32" else (TOL_FAST_L2, TOL_FAST_MAX)
+    _close(out[:1], arr["expected"], *tol)
+    assert torch.equal(m(ir, vis), out)
+    half = batch // 2
+    lo, hi = m(ir[:half].contiguous(), vis[:half].contiguous()), m(ir[half:].contiguous(), vis[half:].contiguous())
+    assert torch.equal(torch.cat([lo, hi]), out)
+    one = m(ir[batch - 3:batch - 2].contiguous(), vis[batch - 3:batch - 2].contiguous())
+    assert torch.equal(one, out[batch - 3:batch - 2])
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+def test_full_size_config3_b16_512(precision):
+    """BASELINE config 3 at full size: B=16 512x512, win 8 (65 536 level-0 windows, 256x256 merge maps)."""
+    _full_size_properties("win8", "model_win8_512_default", 16, 512, precision)
+
+
+def test_full_size_config5_b8_1024_win16():
+    """BASELINE config 5 at full size: B=8 1024x1024, win 16 (t = 256 tokens per window), fast tier (the tier the
+    benchmark measures; the exact tier at this size is covered at B=1 512x512 by model_win16_512)."""
+    _full_size_properties("win16", "model_win16_1024_default", 8, 1024, "fast")
+
+
+def test_reference_checkpoint_to_gpu_forward(tmp_path):
+    """a checkpoint in the reference's on-disk format (a016:243-249: model_state + optimizer / scheduler
+    state + epoch) -> load_reference_checkpoint (weights_only loader, strict 3139-style key set) -> HIP forward ->
+    oracle on the same weights (a017:50-54 then a017:72)."""
+    cfg = CONFIGS["win8_4stage"]
+    src = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(src, seed=17, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in src.state_dict().items()}
+    path = tmp_path / "state.pth"
+    torch.save({"model_state": src.state_dict(), "optimizer_state": {"state": {}, "param_groups": []},
+                "scheduler_state": {"last_epoch": 3}, "current_epoch": 3}, path)
+    m = MyModel(**cfg.model_kwargs(_elu())).eval().to(DEV)
+    extra = m.load_reference_checkpoint(str(path))
+    assert extra["current_epoch"] == 3 and "optimizer_state" in extra
+    ir, vis = (torch.from_numpy(a) for a in synthetic_pair(2, 128, 128, seed_ir=21, seed_vis=22))
+    ref = O.model_forward(sd, cfg, ir, vis)
+    for precision, tol in (("fp32", (5e-5, None)), ("fast", (TOL_FAST_L2, TOL_FAST_MAX))):
+        m.precision = precision
+        _close(m(ir.to(DEV), vis.to(DEV)), ref, *tol)
+
+
+def _mirror_x_into_y(model):
+    """copy every x-stream parameter over its y-stream twin: the two streams then compute the same function"""
+    sd = model.state_dict()
+    pairs = (("window_attention_x.", "window_attention_y."), ("mlp_x_", "mlp_y_"), ("sequence_x.", "sequence_y."),
+             ("norm_layer_1.", "norm_layer_2."), ("mlp_layer_x.", "mlp_layer_y."), ("layer_norm_x.", "layer_norm_y."))
+    new = dict(sd)
+    for k, v in sd.items():
+        for a, b in pairs:
+            if a in k and k.replace(a, b) in sd:
+                new[k.replace(a, b)] = v.clone()
+    model.load_state_dict(new, strict=True)
+
+
+def test_model_first_forward_identical_streams_guard():
+    """a005:98-118: on a model's first forward the reference tests `(x == y).all()` in front of every cross-attention
+    block and calls exit(); here MyModel.forward raises ValueError (and the oracle does too).  With mirrored stream
+    weights and ir == vis the two streams stay identical up to the first cross block."""
+    cfg = CONFIGS["tiny"]
+    m = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(m, seed=5, flavor="stress")
+    _mirror_x_into_y(m)
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ir, _ = (torch.from_numpy(a) for a in synthetic_pair(1, 16, 16))
+    with pytest.raises(ValueError):
+        O.model_forward(sd, cfg, ir, ir.clone())
+    m.to(DEV)
+    for precision in ("fp32", "fast"):
+        m.precision = precision
+        m.input_compatibility_with_cross_option = None
+        with pytest.raises(ValueError):
+            m(ir.to(DEV), ir.clone().to(DEV))
+        assert m.input_compatibility_with_cross_option is False
+    # distinct inputs pass the check once, later forwards skip it (as the reference does)
+    ok = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(ok, seed=5, flavor="stress")
+    ok.to(DEV)
+    a, b = (torch.from_numpy(t).to(DEV) for t in synthetic_pair(1, 16, 16))
+    first = ok(a, b)
+    assert ok.input_compatibility_with_cross_option is True
+    assert torch.equal(ok(a, b), first)
+
+
+def test_sharded_fusion_graph_replay_follows_weights_and_inputs():
+    """ShardedFusion(use_graph=True) at world_size 1 — the path bench.py times: replay == eager for different inputs, the
+    caller's tensors are never adopted or mutated, and load_state_dict / a precision change re-capture instead of
+    replaying freed weight addresses."""
+    cfg = CONFIGS["win8_4stage"]
+    m = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(m, seed=0, flavor="default")
+    m.to(DEV)
+    runner = ShardedFusion(m, world_size=1, rank=0, use_graph=True)
+    ir1, vis1 = (torch.from_numpy(a).to(DEV) for a in synthetic_pair(2, 128, 128, 1, 2))
+    ir2, vis2 = (torch.from_numpy(a).to(DEV) for a in synthetic_pair(2, 128, 128, 3, 4))
+    keep = ir1.clone()
+    o1 = runner.step(ir1, vis1).clone()
+    assert runner.graph_active and runner.captures == 1
+    assert torch.equal(o1, m(ir1, vis1))
+    o2 = runner.step(ir2, vis2).clone()
+    assert runner.captures == 1 and torch.equal(o2, m(ir2, vis2)) and not torch.equal(o1, o2)
+    assert torch.equal(ir1, keep)                       # the first batch was copied, not adopted as the static buffer
+    other = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(other, seed=9, flavor="stress")
+    m.load_state_dict(other.state_dict(), strict=True)   # drops the arena and the packed images the graph points at
+    o3 = runner.step(ir1, vis1).clone()
+    assert runner.captures == 2
+    assert torch.equal(o3, m(ir1, vis1)) and not torch.equal(o3, o1)
+    assert torch.equal(o3, other.to(DEV)(ir1, vis1))
+    m.precision = "fp32"
+    o4 = runner.step(ir1, vis1).clone()
+    assert runner.captures == 3 and torch.equal(o4, m(ir1, vis1)) and not torch.equal(o4, o3)
+    assert torch.equal(runner.fuse_global(ir2, vis2), m(ir2, vis2))
 
 
 def test_load_state_dict_roundtrip_refreshes_arena():

@@ -44,6 +44,17 @@ def test_basic_block(name):
     _check(ox, arr["expected_x"]); _check(oy, arr["expected_y"])
 
 
+@pytest.mark.parametrize("name", G.cases("normal_and_shift_block_pair"))
+def test_normal_and_shift_block_pair(name):
+    meta, arr = G.load(name)
+    c = meta["ctor"]
+    sd = G.recipe_state(meta)
+    x, y = G.randn(meta["in_shape"], meta["seed_x"]), G.randn(meta["in_shape"], meta["seed_y"])
+    ox, oy = O.normal_and_shift_block_pair(sd, "", x, y, cross=c["use_cross_attr"], num_heads=c["num_heads"],
+                                           dims_per_head=c["dims_per_head"], window_size=tuple(c["window_size"]))
+    _check(ox, arr["expected_x"]); _check(oy, arr["expected_y"])
+
+
 @pytest.mark.parametrize("name", G.cases("self_and_cross_block_pair"))
 def test_self_and_cross_block_pair(name):
     meta, arr = G.load(name)

@@ -1,5 +1,5 @@
 # PMC passes over one BasicBlock launch loop (tools/profile_block.py), one rocprofv3 --pmc run per counter group.
-#   bash tools/pmc_block.sh <level> <outdir-under-gpurun_out> [groups...]
+#   bash tools/pmc_block.sh <level> <outdir-under-gpurun_out> [groups...]      (PB_EXTRA="--decoder 1" adds profile_block.py arguments)
 set -e
 LEVEL=${1:-1}
 O=gpurun_out/${2:-pmc_l$LEVEL}
@@ -7,7 +7,7 @@ shift 2 || true
 GROUPS_="${@:-g1 g2 g3 g4 g5}"
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 mkdir -p $O
-run() { n=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $O/$n -o p -- python3 tools/profile_block.py --level $LEVEL --iters 10 > $O.$n.log 2>&1; }
+run() { n=$1; shift; rocprofv3 --pmc "$@" --output-format csv -d $O/$n -o p -- python3 tools/profile_block.py --level $LEVEL --iters 10 $PB_EXTRA > $O.$n.log 2>&1; }
 for g in $GROUPS_; do
   case $g in
     g1) run g1 SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY ;;
