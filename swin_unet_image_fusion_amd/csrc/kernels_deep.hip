@@ -200,9 +200,11 @@ __global__ __launch_bounds__(256) void gemm_sp_kernel(SpBatchDev batch, int M, i
                     const f16x4 h = {(_Float16)v.x, (_Float16)v.y, (_Float16)v.z, (_Float16)v.w};
                     *reinterpret_cast<f16x4*>(pr.o_hi + (int64_t)m * N + n) = h;
                 } else {
+                    // Q (pre-scaled) and K in f16 too: the Q.K^T operands are 8x closer to fp32 than in bf16 at the same MFMA rate
+                    typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
                     const float sc = which == 0 ? batch.qscale : 1.0f;
-                    const bf16x4 h = {(bf16)(v.x * sc), (bf16)(v.y * sc), (bf16)(v.z * sc), (bf16)(v.w * sc)};
-                    *reinterpret_cast<bf16x4*>(pr.o_hi + (int64_t)m * N + n) = h;
+                    const f16x4 h = {(_Float16)(v.x * sc), (_Float16)(v.y * sc), (_Float16)(v.z * sc), (_Float16)(v.w * sc)};
+                    *reinterpret_cast<f16x4*>(pr.o_hi + (int64_t)m * N + n) = h;
                 }
             } else if (epi == SP_EPI_ELU_SPLIT) {
                 v.x = elu_1(v.x); v.y = elu_1(v.y); v.z = elu_1(v.z); v.w = elu_1(v.w);

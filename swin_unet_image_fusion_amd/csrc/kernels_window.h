@@ -34,8 +34,8 @@ int launch_attn_core_mfma(const float* const* Q, const float* const* K, const fl
                           int heads, int head_dim, int shift, hipStream_t stream, unsigned short* const* O_hi = nullptr,
                           unsigned short* const* O_lo = nullptr, const unsigned short* const* Q16 = nullptr,
                           const unsigned short* const* K16 = nullptr, const unsigned short* const* V16 = nullptr);
-// Q16 / K16 / V16 non-null (head_dim % 4 == 0): the operands come in the core's own formats — Q bf16 pre-scaled by
-// d^-0.5 * log2(e), K bf16, V fp16 (row strides ldq / ldk / ldv in elements) — as written by the deep-level Q/K/V GEMM
+// Q16 / K16 / V16 non-null (head_dim % 4 == 0): the operands come in the core's own formats — Q f16 pre-scaled by
+// d^-0.5 * log2(e), K f16, V f16 (row strides ldq / ldk / ldv in elements) — as written by the deep-level Q/K/V GEMM
 // epilogue (SP_EPI_QKV16); Q / K / V are then ignored.
 // O_hi / O_lo non-null (head_dim % 4 == 0): the output is written as split-bf16 planes hi = bf16(o), lo = bf16(o - hi)
 // with row stride ldo instead of fp32 O (input format of the deep-level projection GEMM, kernels_deep.h).

@@ -283,8 +283,8 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     bf16* ahi = reinterpret_cast<bf16*>(smem + G::l_ahi);
     bf16* alo = reinterpret_cast<bf16*>(smem + G::l_alo);
-    bf16* qimg = reinterpret_cast<bf16*>(smem + G::l_q);
-    bf16* kimg = reinterpret_cast<bf16*>(smem + G::l_k);
+    f16* qimg = reinterpret_cast<f16*>(smem + G::l_q);   // Q (pre-scaled) and K images: f16 (Q.K^T operands; same MFMA rate as bf16, 8x the mantissa)
+    f16* kimg = reinterpret_cast<f16*>(smem + G::l_k);
     f16* vt = reinterpret_cast<f16*>(smem + G::l_vt);
     uint4* maskt = reinterpret_cast<uint4*>(smem + G::l_mask);
 
@@ -414,15 +414,15 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
                     const f32x4 ak = mma_bf16x3<KS>(wk, x[tt], z4);
                     const f32x4 av = mma_bf16x3<KS>(x[tt], wv, z4);   // [token 4g+j][channel r16]
                     if (ch4 < G::KC) {   // columns C..KC-1 are the K padding: rewritten as zeros (the MLP's hidden chunks reuse these rows)
-                        bf16x4 q4 = {0, 0, 0, 0}, k4 = {0, 0, 0, 0};
+                        f16x4 q4 = {0, 0, 0, 0}, k4 = {0, 0, 0, 0};
                         if (ch4 < C) {
                             const float4 bq = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bqkv + ch4);
                             const float4 bk = *reinterpret_cast<const float4*>(wvec(kvs) + G::v_bqkv + C + ch4);
-                            q4 = bf16x4{(bf16)(aq[0] + bq.x), (bf16)(aq[1] + bq.y), (bf16)(aq[2] + bq.z), (bf16)(aq[3] + bq.w)};
-                            k4 = bf16x4{(bf16)(ak[0] + bk.x), (bf16)(ak[1] + bk.y), (bf16)(ak[2] + bk.z), (bf16)(ak[3] + bk.w)};
+                            q4 = f16x4{(f16)(aq[0] + bq.x), (f16)(aq[1] + bq.y), (f16)(aq[2] + bq.z), (f16)(aq[3] + bq.w)};
+                            k4 = f16x4{(f16)(ak[0] + bk.x), (f16)(ak[1] + bk.y), (f16)(ak[2] + bk.z), (f16)(ak[3] + bk.w)};
                         }
-                        *reinterpret_cast<bf16x4*>(qimg + (ws * T + trow + r16) * LDC + ch4) = q4;
-                        *reinterpret_cast<bf16x4*>(kimg + (kvs * T + trow + r16) * LDC + ch4) = k4;
+                        *reinterpret_cast<f16x4*>(qimg + (ws * T + trow + r16) * LDC + ch4) = q4;
+                        *reinterpret_cast<f16x4*>(kimg + (kvs * T + trow + r16) * LDC + ch4) = k4;
                     }
                     const int chv = nt * 16 + r16;
                     if (chv < C) {
@@ -454,9 +454,9 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
 #pragma unroll
                     for (int i = 0; i < 16; ++i) bfr[kt][i] = bias4[(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hf) * T + 32 * qb + r];
             }
-            const bf16* qrow = qimg + (s * T + 32 * qb + r) * LDC + 8 * hf;
-            const bf16* krow0 = kimg + (s * T + r) * LDC + 8 * hf;
-            const bf16* krow1 = krow0 + 32 * LDC;
+            const f16* qrow = qimg + (s * T + 32 * qb + r) * LDC + 8 * hf;
+            const f16* krow0 = kimg + (s * T + r) * LDC + 8 * hf;
+            const f16* krow1 = krow0 + 32 * LDC;
             constexpr int HEAD_UNROLL = (G::NTK <= 2 && TT == 1) ? SWF_HEAD_UNROLL_C24 : 1;   // heads in flight while the residual registers are few
 #pragma unroll HEAD_UNROLL
             for (int hh = 0; hh < 4 * TT; ++hh) {
@@ -470,17 +470,17 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
                     const uint4 mk = maskt[(head * G::NKS + ks_lo) * 2 + hf];
                     uint4 qv = *reinterpret_cast<const uint4*>(qrow + ks_lo * 16);
                     qv.x &= mk.x; qv.y &= mk.y; qv.z &= mk.z; qv.w &= mk.w;
-                    const bf16x8 qf = __builtin_bit_cast(bf16x8, qv);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow0 + ks_lo * 16), qf, bfr[0], 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow1 + ks_lo * 16), qf, bfr[1], 0, 0, 0);
+                    const f16x8 qf = __builtin_bit_cast(f16x8, qv);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow0 + ks_lo * 16), qf, bfr[0], 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow1 + ks_lo * 16), qf, bfr[1], 0, 0, 0);
                 }
                 for (int ks = ks_lo + 1; ks <= ks_hi; ++ks) {
                     const uint4 mk = maskt[(head * G::NKS + ks) * 2 + hf];
                     uint4 qv = *reinterpret_cast<const uint4*>(qrow + ks * 16);
                     qv.x &= mk.x; qv.y &= mk.y; qv.z &= mk.z; qv.w &= mk.w;
-                    const bf16x8 qf = __builtin_bit_cast(bf16x8, qv);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow0 + ks * 16), qf, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(*reinterpret_cast<const bf16x8*>(krow1 + ks * 16), qf, acc1, 0, 0, 0);
+                    const f16x8 qf = __builtin_bit_cast(f16x8, qv);
+                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow0 + ks * 16), qf, acc0, 0, 0, 0);
+                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow1 + ks * 16), qf, acc1, 0, 0, 0);
                 }
                 // row max over the lane's 32 keys with v_max3 (hipcc would emit canonicalising v_max pairs), then
                 // across the two lane halves
@@ -623,8 +623,8 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
             // the Q / K rows it wrote for this window (dead since the post-attention barrier; the projections of
             // the next window rewrite them, K padding included)
             // (QALO: no Q image — both halves of the second buffer share the K rows, hi in columns 0-31, lo in 32-63)
-            bf16* const krows = kimg + ((args.cross ? 1 - ws : ws) * T + wm0 * 16) * LDC;
-            bf16* hb_hi[2] = {my_ahi, G::QALO ? krows : qimg + (ws * T + wm0 * 16) * LDC};
+            bf16* const krows = reinterpret_cast<bf16*>(kimg) + ((args.cross ? 1 - ws : ws) * T + wm0 * 16) * LDC;   // dead K rows, reused as a bf16 image
+            bf16* hb_hi[2] = {my_ahi, G::QALO ? krows : reinterpret_cast<bf16*>(qimg) + (ws * T + wm0 * 16) * LDC};
             bf16* hb_lo[2] = {my_alo, G::QALO ? krows + 32 : krows};
             if constexpr (!ROT) {
             constexpr int HC_UNROLL = G::WLDS ? G::KH / 32 : (ROOMY ? 3 : 2);   // L2-sourced weights: full unrolling hoists every fragment load and spills
@@ -780,8 +780,8 @@ __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
     constexpr int T = 64, WH = 8, WW = 8, QS = cround(D, 8), QKS = cceil(D, 16), MT = cceil(D, 32), TW = 2 * WW - 1, VRS = T + 8;
     constexpr int VEC = (D % 4 == 0) ? 4 : ((D % 2 == 0) ? 2 : 1);   // floats per global load of a head's channel run
     constexpr int CPT = D / VEC, NCHUNK = T * CPT, NIT = cceil(NCHUNK, 128);
-    __shared__ __attribute__((aligned(16))) bf16 qimg[T * QS];
-    __shared__ __attribute__((aligned(16))) bf16 kimg[T * QS];
+    __shared__ __attribute__((aligned(16))) f16 qimg[T * QS];
+    __shared__ __attribute__((aligned(16))) f16 kimg[T * QS];
     __shared__ __attribute__((aligned(16))) f16 vt[D * VRS];
     __shared__ float tab[(2 * WH - 1) * TW];
 
@@ -796,8 +796,8 @@ __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
     if constexpr (QS != D) {   // K padding of the Q / K rows
         for (int i = tid; i < T * (QS - D); i += 128) {
             const int tok = i / (QS - D), c = D + i % (QS - D);
-            qimg[tok * QS + c] = (bf16)0.f;
-            kimg[tok * QS + c] = (bf16)0.f;
+            qimg[tok * QS + c] = (f16)0.f;
+            kimg[tok * QS + c] = (f16)0.f;
         }
     }
     if constexpr (VEC == 4) {
@@ -865,8 +865,8 @@ __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
             const int vp = vt_pos(tok);
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                qimg[tok * QS + c0 + j] = (bf16)(qv[it][j] * qscale);
-                kimg[tok * QS + c0 + j] = (bf16)kv[it][j];
+                qimg[tok * QS + c0 + j] = (f16)(qv[it][j] * qscale);
+                kimg[tok * QS + c0 + j] = (f16)kv[it][j];
                 vt[(c0 + j) * VRS + vp] = (f16)vv[it][j];
             }
         }
@@ -876,10 +876,10 @@ staged:
     __syncthreads();
 
     const int r = lane & 31, hf = lane >> 5;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int q = 32 * qb + r, qy = q >> 3, qx = q & 7;
     const bool last_row = a.shift && wy == nwy - 1, last_col = a.shift && wx == nwx - 1;
-    const bf16* qrow = qimg + q * QS;
+    const f16* qrow = qimg + q * QS;
     f32x16 acc[2];
     // accumulator init = relative-position bias (+ shift mask), exp2 units.  Register i of key tile kt is key row
     // ky = 4*kt + (i>>2), column kx = (i&3) + 4*hf  (C/D map of the 32x32 MFMA with 8 keys per window row).
@@ -895,15 +895,15 @@ staged:
         }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-        const bf16* krow = kimg + (32 * kt + r) * QS;
+        const f16* krow = kimg + (32 * kt + r) * QS;
 #pragma unroll
         for (int ks = 0; ks < QKS; ++ks) {
-            bf16x8 ka = zero8, qf = zero8;
+            f16x8 ka = zero8, qf = zero8;
             if (ks * 16 + 8 * hf + 8 <= QS) {
-                ka = *reinterpret_cast<const bf16x8*>(krow + ks * 16 + 8 * hf);
-                qf = *reinterpret_cast<const bf16x8*>(qrow + ks * 16 + 8 * hf);
+                ka = *reinterpret_cast<const f16x8*>(krow + ks * 16 + 8 * hf);
+                qf = *reinterpret_cast<const f16x8*>(qrow + ks * 16 + 8 * hf);
             }
-            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf, acc[kt], 0, 0, 0);
+            acc[kt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf, acc[kt], 0, 0, 0);
         }
     }
     float mx = max3f(acc[0][0], acc[0][1], acc[1][0]);
@@ -1014,8 +1014,8 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     constexpr int VEC = (D % 4 == 0) ? 4 : ((D % 2 == 0) ? 2 : 1);
     constexpr int CPT = D / VEC, NCHUNK = T * CPT, NIT = cceil(NCHUNK, 512);
     extern __shared__ __attribute__((aligned(16))) char sm16[];
-    bf16* qimg = reinterpret_cast<bf16*>(sm16);                    // [256][QS]
-    bf16* kimg = qimg + T * QS;
+    f16* qimg = reinterpret_cast<f16*>(sm16);                    // [256][QS]
+    f16* kimg = qimg + T * QS;
     f16* vt = reinterpret_cast<f16*>(kimg + T * QS);               // [D + 1][VRS]; row D = 1.0
     constexpr int TW = 2 * WW - 1, NTAB = (2 * WH - 1) * TW;
     float* tab = reinterpret_cast<float*>(sm16 + (size_t(2) * T * QS * 2 + size_t(D + 1) * VRS * 2 + 15) / 16 * 16);   // [31][31], exp2 units
@@ -1032,8 +1032,8 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     if constexpr (QS != D) {
         for (int i = tid; i < T * (QS - D); i += 512) {
             const int tok = i / (QS - D), c = D + i % (QS - D);
-            qimg[tok * QS + c] = (bf16)0.f;
-            kimg[tok * QS + c] = (bf16)0.f;
+            qimg[tok * QS + c] = (f16)0.f;
+            kimg[tok * QS + c] = (f16)0.f;
         }
     }
     float qv[NIT][VEC], kv[NIT][VEC], vv[NIT][VEC];
@@ -1060,8 +1060,8 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
             const int vpos = (tok & ~15) | (((k16 >> 2) & 1) << 3) | (((k16 >> 3) << 2) | (k16 & 3));   // vt_pos for any number of key tiles
 #pragma unroll
             for (int j = 0; j < VEC; ++j) {
-                qimg[tok * QS + c0 + j] = (bf16)(qv[it][j] * qscale);
-                kimg[tok * QS + c0 + j] = (bf16)kv[it][j];
+                qimg[tok * QS + c0 + j] = (f16)(qv[it][j] * qscale);
+                kimg[tok * QS + c0 + j] = (f16)kv[it][j];
                 vt[(c0 + j) * VRS + vpos] = (f16)vv[it][j];
             }
         }
@@ -1069,7 +1069,7 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     __syncthreads();
 
     const int r = lane & 31, hf = lane >> 5;
-    const bf16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
+    const f16x8 zero8 = {0, 0, 0, 0, 0, 0, 0, 0};
     const int q = 32 * qb + r;
     // relative-position bias (a001:113-144) from the 31x31 table in LDS, shift mask (a001:217-315) by index arithmetic: only
     // windows in the last window row / column of a shifted block hold two region labels, split at wh/2 (ww/2).  (A
@@ -1079,10 +1079,10 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     const bool colmask0 = vcol && (qx >= WW - WW / 2), colmask1 = vcol && !(qx >= WW - WW / 2);   // key column half 0 / 1 masked for this query
     const float* tq = tab + (WH - 1 - qy) * TW + (WW - 1 - qx) + 4 * hf;
     constexpr float NEG = -1e10f * kLog2e;
-    bf16x8 qf[QKS];
+    f16x8 qf[QKS];
 #pragma unroll
     for (int ks = 0; ks < QKS; ++ks)
-        qf[ks] = (ks * 16 + 8 * hf + 8 <= QS) ? *reinterpret_cast<const bf16x8*>(qimg + q * QS + ks * 16 + 8 * hf) : zero8;
+        qf[ks] = (ks * 16 + 8 * hf + 8 <= QS) ? *reinterpret_cast<const f16x8*>(qimg + q * QS + ks * 16 + 8 * hf) : zero8;
     f32x16 o[MT];
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1098,11 +1098,11 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
             const bool rowmask = vrow && ((2 * kt + (i >> 3) >= WH - WH / 2) != (qy >= WH - WH / 2));
             acc[i] = (rowmask || (((i >> 2) & 1) ? colmask1 : colmask0)) ? NEG : bv;
         }
-        const bf16* krow = kimg + (32 * kt + r) * QS;
+        const f16* krow = kimg + (32 * kt + r) * QS;
 #pragma unroll
         for (int ks = 0; ks < QKS; ++ks) {
-            const bf16x8 ka = (ks * 16 + 8 * hf + 8 <= QS) ? *reinterpret_cast<const bf16x8*>(krow + ks * 16 + 8 * hf) : zero8;
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ks], acc, 0, 0, 0);
+            const f16x8 ka = (ks * 16 + 8 * hf + 8 <= QS) ? *reinterpret_cast<const f16x8*>(krow + ks * 16 + 8 * hf) : zero8;
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ka, qf[ks], acc, 0, 0, 0);
         }
         float mt_ = max3f(acc[0], acc[1], acc[2]);
 #pragma unroll
