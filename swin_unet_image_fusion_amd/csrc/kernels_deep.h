@@ -48,6 +48,7 @@ struct DeepWeights {   // views into one packed image
     // fc1 / fc2 again in MFMA-fragment-major order for the fused MLP kernel (kernels_mlp.hip), or nullptr:
     // block (row tile rt of 32 rows, k16 step ks) = 64 lanes x 8 bf16, lane = 32*hf + r holds row 32rt+r, k = 16ks+8hf..+7
     const bf16_raw *w1f_hi, *w1f_lo, *w2f_hi, *w2f_lo;
+    const void* qa;   // section of the fused Q/K/V + attention kernel (kernels_qkvattn.h), or nullptr
 };
 DeepWeights deep_block_views(const swf_block_desc& d, const void* packed);
 

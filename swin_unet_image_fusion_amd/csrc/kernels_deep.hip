@@ -12,6 +12,7 @@
 #include "kernels_deep.h"
 #include "kernels_window.h"
 #include "kernels_mlp.h"
+#include "kernels_qkvattn.h"
 
 #include <algorithm>
 #include <mutex>
@@ -369,9 +370,11 @@ bool deep_block_supported(const swf_block_desc& d) {
            attn_core_mfma_supported(d.attn.win_h, d.attn.win_w, d.attn.head_dim);
 }
 
+static size_t deep_planes_bytes(const swf_block_desc& d) { return align_up((size_t)deep_sizes(d).total * 4, 256); }   // hi + lo planes, 2 bytes each
+
 size_t deep_block_packed_bytes(const swf_block_desc& d) {
     if (!deep_block_supported(d)) return 0;
-    return align_up((size_t)deep_sizes(d).total * 4, 256);   // hi + lo planes, 2 bytes each
+    return deep_planes_bytes(d) + qkvattn_packed_bytes(d);   // + the fused Q/K/V + attention kernel's section, where it applies
 }
 
 DeepWeights deep_block_views(const swf_block_desc& d, const void* packed) {
@@ -391,6 +394,7 @@ DeepWeights deep_block_views(const swf_block_desc& d, const void* packed) {
         w.w1f_hi = hi + o; w.w1f_lo = lo + o; o += s.w1;
         w.w2f_hi = hi + o; w.w2f_lo = lo + o;
     }
+    w.qa = qkvattn_packed_bytes(d) ? static_cast<const char*>(packed) + deep_planes_bytes(d) : nullptr;
     return w;
 }
 
@@ -419,6 +423,7 @@ int pack_deep_block(const swf_block_desc& d, const swf_block_stream_params& p, v
             o += n2;
         }
     }
+    if (qkvattn_packed_bytes(d)) SWF_TRY(pack_qkvattn(d, p, static_cast<char*>(packed) + deep_planes_bytes(d), stream));
     return SWF_OK;
 }
 

@@ -55,6 +55,9 @@ constexpr float kLog2e = 1.4426950408889634f, kLn2 = 0.6931471805599453f;
 #ifndef W24_MED3
 #define W24_MED3 1       // ELU in exp2 units through one v_med3 (fc1 packed with log2 e, fc2 with ln 2)
 #endif
+#ifndef W24_ACT_F16
+#define W24_ACT_F16 0    // A/B: activations of the linear layers as ONE f16 (weights split into f16 hi + lo, 2 MFMAs per k-step) instead of split-bf16 x3
+#endif
 #ifndef W24_WAVES
 #define W24_WAVES 3   // resident workgroups per CU = waves per SIMD (register budget 512 / W24_WAVES)
 #endif
@@ -98,15 +101,32 @@ __device__ __forceinline__ f32x16 mfma_f16(u32x4 a, u32x4 b, f32x16 c) {
 }
 // acc += a . b over one 16-deep k-step with split-bf16 operands (a = a_hi + a_lo, b = b_hi + b_lo): three MFMAs, small cross
 // terms first so they are not absorbed by the large hi.hi partial sums
+template <bool WEIGHT_IS_A = true>
 __device__ __forceinline__ f32x16 mma3(u32x4 ahi, u32x4 alo, u32x4 bhi, u32x4 blo, f32x16 acc) {
+    if constexpr (W24_ACT_F16) {   // the activation operand is a single f16 fragment (its "lo" is unused), the weight f16 hi + lo
+        if constexpr (WEIGHT_IS_A) {
+            acc = mfma_f16(alo, bhi, acc);
+            acc = mfma_f16(ahi, bhi, acc);
+        } else {
+            acc = mfma_f16(ahi, blo, acc);
+            acc = mfma_f16(ahi, bhi, acc);
+        }
+        return acc;
+    }
     acc = mfma_bf16(alo, bhi, acc);
     acc = mfma_bf16(ahi, blo, acc);
     acc = mfma_bf16(ahi, bhi, acc);
     return acc;
 }
 
+__device__ __forceinline__ u32x4 pack8_f16(const float* v);
 // 8 fp32 values -> one k-step fragment in split-bf16 (hi = bf16(v), lo = bf16(v - hi))
 __device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+    if constexpr (W24_ACT_F16) {
+        hi = pack8_f16(v);
+        lo = hi;   // unused
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < 4; ++p) {
         const bf16x2 h = {(bf16)v[2 * p], (bf16)v[2 * p + 1]};
@@ -367,7 +387,7 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
             // V: tokens in rows (A = x fragments, B = weight fragments): register i of lane (channel r, hf) is token rho(i, hf)
             acc = zero16;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) acc = mma3(xh[s], xl[s], WK(G::F_QKV + 8 + 2 * s), WK(G::F_QKV + 9 + 2 * s), acc);
+            for (int s = 0; s < 2; ++s) acc = mma3<false>(xh[s], xl[s], WK(G::F_QKV + 8 + 2 * s), WK(G::F_QKV + 9 + 2 * s), acc);
 #pragma unroll
             for (int i = 0; i < 16; ++i) t[i] = acc[i];
             u32x4* vdst = vimg + ((buf * 2 + kvs) * 4 + 2 * qb) * 64 + lane;
@@ -539,8 +559,13 @@ __global__ __launch_bounds__(256) void pack24_kernel(Pack24Args a) {
             const int hid = 32 * (u >> 1) + rho(8 * (u & 1) + e, hf);
             if (r < 24) val = hid < HID ? lin(p.fc2, r, hid, HID) * (W24_MED3 ? kLn2 : 1.0f) : ((G::ONES_H && hid == HID) ? bia(p.fc2, r) : 0.f);   // h' = ELU log2(e)
         }
-        const bf16 hi = (bf16)val;
-        reinterpret_cast<bf16*>(dst)[idx] = hl ? (bf16)(val - (float)hi) : hi;
+        if constexpr (W24_ACT_F16) {
+            const f16 hi = (f16)val;
+            reinterpret_cast<f16*>(dst)[idx] = hl ? (f16)(val - (float)hi) : hi;
+        } else {
+            const bf16 hi = (bf16)val;
+            reinterpret_cast<bf16*>(dst)[idx] = hl ? (bf16)(val - (float)hi) : hi;
+        }
     }
     float* vec = reinterpret_cast<float*>(dst + G::p_vec);
     for (int i = gtid; i < 128; i += gsz) {

@@ -13,6 +13,7 @@
 #include "kernels_deep.h"
 #include "kernels_patch.h"
 #include "kernels_mlp.h"
+#include "kernels_qkvattn.h"
 
 namespace swf {
 
@@ -274,6 +275,16 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         for (int s = 0; s < nstream; ++s) l1.p[s] = LnProb{xin[s], nullptr, pp[s]->ln1.gamma, pp[s]->ln1.beta, xn_hi[s], xn_lo[s]};
         SWF_TRY(launch_layernorm(l1, nstream, N, C, 0, stream));
     }
+    static const bool no_qkvattn = std::getenv("SWF_NO_QKVATTN") != nullptr;   // A/B switch
+    const bool fused_attn = !no_qkvattn && qkvattn_supported(*desc) && wv[0].qa && (nstream == 1 || wv[1].qa) && N <= INT32_MAX / 256;
+    if (fused_attn) {   // Q/K/V projections + window attention in one launch
+        QkvAttnArgs qa{};
+        for (int s = 0; s < nstream; ++s) {
+            qa.packed[s] = wv[s].qa; qa.xn_hi[s] = xn_hi[s]; qa.xn_lo[s] = xn_lo[s]; qa.o_hi[s] = o_hi[s]; qa.o_lo[s] = o_lo[s];
+        }
+        qa.B = B; qa.H = H; qa.W = W; qa.shift = desc->attn.shift; qa.cross = cross;
+        SWF_TRY(launch_qkvattn(*desc, qa, nstream, stream));
+    }
     SpGemmBatch gq{};
     for (int s = 0; s < nstream; ++s) {
         const int kvs = cross ? 1 - s : s;   // K and V of stream s read the other stream's normalised tokens in a cross block
@@ -286,8 +297,8 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         }
     }
     gq.qscale = 1.4426950408889634f / std::sqrt((float)desc->attn.head_dim);   // d^-0.5 (a001:32-34) and exp -> exp2
-    SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_QKV16, stream));
-    {
+    if (!fused_attn) SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_QKV16, stream));
+    if (!fused_attn) {
         const bf16_raw* qq[2] = {qkv[0][0], qkv[1][0]};
         const bf16_raw* kk[2] = {qkv[0][1], qkv[1][1]};
         const bf16_raw* vv[2] = {qkv[0][2], qkv[1][2]};
