@@ -96,6 +96,13 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 }
 #define QA_FENCE() asm volatile("" ::: "memory")
 
+#ifdef QA_PROBE   // diagnostic build: 10-ns wall-clock stamps of workgroup QA_PROBE, wave 0, into a buffer nothing else reads
+__device__ unsigned long long qa_probe[8];
+#define QA_STAMP(i) do { if (blockIdx.x == QA_PROBE && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) qa_probe[i] = wall_clock64(); } while (0)
+#else
+#define QA_STAMP(i) do { } while (0)
+#endif
+
 template <int C>
 __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
     using G = QA<C>;
@@ -121,42 +128,57 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
         return (b * H + oy) * W + ox;
     };
 
-    // ---- stage the window's LayerNorm rows: 2 planes x 64 rows x C bf16, row-major, stride XS ----
-    {
-        constexpr int CPR = C / 8, NCH = 2 * 64 * CPR;   // 16-byte chunks per row / per tile
-        const int ntile = cross ? 2 : 1;
-        for (int c = tid; c < ntile * NCH; c += 512) {
-            const int tile = c / NCH, rem = c - tile * NCH, plane = rem / (64 * CPR), rem2 = rem - plane * 64 * CPR;
-            const int row = rem2 / CPR, j = rem2 - row * CPR;
-            const int s_src = tile ? kvs : st;
-            const bf16* src = (plane ? a.xn_lo[s_src] : a.xn_hi[s_src]) + (int64_t)tok_index(row) * C + j * 8;
-            *reinterpret_cast<u32x4*>(smem + tile * G::l_tile + plane * G::l_plane + row * XS + j * 16) = *reinterpret_cast<const u32x4*>(src);
-        }
-    }
-    __syncthreads();
-
-    // ---- Q, K, V tiles of (head, token half): K = C in 16-deep steps; weight fragments from L2, one step ahead ----
+    QA_STAMP(0);
+    // ---- weight fragments: a register ring PD k-steps deep, filled before anything else so the first L2 round trips run
+    //      under the staging of the token rows ----
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(a.packed[st])), 0, (int)G::p_total, 0x00020000);
     const unsigned loff = (unsigned)lane * 16u;
     const int fbase = head * 3 * KS * 2;   // fragment index of (head, q, step 0, hi)
     auto WFRAG = [&](int m, int s, int hl2) {
         return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, ((fbase + (m * KS + s) * 2 + hl2)) * 1024, 0));
     };
+    constexpr int PD = 4;
+    u32x4 w[PD][6];
+#pragma unroll
+    for (int p = 0; p < PD && p < KS; ++p)
+#pragma unroll
+        for (int m = 0; m < 3; ++m) { w[p][2 * m] = WFRAG(m, p, 0); w[p][2 * m + 1] = WFRAG(m, p, 1); }
+
+    // ---- stage the window's LayerNorm rows: 2 planes x 64 rows x C bf16, row-major, stride XS.  All of a thread's loads are
+    //      issued before its first LDS store (one L2 round trip, not one per chunk) ----
+    {
+        constexpr int CPR = C / 8, NCH = 2 * 64 * CPR, PER = NCH / 512;   // 16-byte chunks per row / per tile / per thread
+        static_assert(NCH % 512 == 0, "chunks per tile must divide evenly over the workgroup");
+        const int ntile = cross ? 2 : 1;
+        for (int tile = 0; tile < ntile; ++tile) {
+            const int s_src = tile ? kvs : st;
+            u32x4 v[PER];
+            int dst[PER];
+#pragma unroll
+            for (int i = 0; i < PER; ++i) {
+                const int rem = tid + 512 * i, plane = rem / (64 * CPR), rem2 = rem - plane * 64 * CPR;
+                const int row = rem2 / CPR, j = rem2 - row * CPR;
+                const bf16* src = (plane ? a.xn_lo[s_src] : a.xn_hi[s_src]) + (int64_t)tok_index(row) * C + j * 8;
+                v[i] = *reinterpret_cast<const u32x4*>(src);
+                dst[i] = tile * (int)G::l_tile + plane * (int)G::l_plane + row * XS + j * 16;
+            }
+#pragma unroll
+            for (int i = 0; i < PER; ++i) *reinterpret_cast<u32x4*>(smem + dst[i]) = v[i];
+        }
+    }
+    __syncthreads();
+    QA_STAMP(1);
+
+    // ---- Q, K, V tiles of (head, token half): K = C in 16-deep steps; weight fragments from the register ring ----
     const char* xq = smem + G::l_xq + (32 * tt + r) * XS + hf * 16;
     const char* xk = smem + (cross ? G::l_xkv : G::l_xq) + (32 * tt + r) * XS + hf * 16;
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 aq = zero16, ak = zero16, av = zero16;
     {
-        u32x4 w[2][6];
-#pragma unroll
-        for (int m = 0; m < 3; ++m) { w[0][2 * m] = WFRAG(m, 0, 0); w[0][2 * m + 1] = WFRAG(m, 0, 1); }
+        // Register ring of weight fragments, PD k-steps deep: with one step of run-ahead every step waited a whole L2 round trip
+        // (12 steps x ~0.7 us); the ring keeps 6 * PD loads (1 KB each) in flight per wave.  Fences pin the issue points.
 #pragma unroll
         for (int s = 0; s < KS; ++s) {
-            QA_FENCE();
-            if (s + 1 < KS) {
-#pragma unroll
-                for (int m = 0; m < 3; ++m) { w[(s + 1) & 1][2 * m] = WFRAG(m, s + 1, 0); w[(s + 1) & 1][2 * m + 1] = WFRAG(m, s + 1, 1); }
-            }
             QA_FENCE();
             const u32x4 xh = *reinterpret_cast<const u32x4*>(xq + s * 32), xl = *reinterpret_cast<const u32x4*>(xq + G::l_plane + s * 32);
             u32x4 kh = xh, kl = xl;
@@ -164,12 +186,18 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
                 kh = *reinterpret_cast<const u32x4*>(xk + s * 32);
                 kl = *reinterpret_cast<const u32x4*>(xk + G::l_plane + s * 32);
             }
-            const u32x4* ws_ = w[s & 1];
+            u32x4 (&ws_)[6] = w[s % PD];
             aq = mma3(ws_[0], ws_[1], xh, xl, aq);   // [virtual channel][token]
             ak = mma3(ws_[2], ws_[3], kh, kl, ak);
             av = mma3(kh, kl, ws_[4], ws_[5], av);   // [token][virtual channel]: the accumulator registers are V^T's key slots
+            QA_FENCE();
+            if (s + PD < KS) {
+#pragma unroll
+                for (int m = 0; m < 3; ++m) { ws_[2 * m] = WFRAG(m, s + PD, 0); ws_[2 * m + 1] = WFRAG(m, s + PD, 1); }
+            }
         }
     }
+    QA_STAMP(2);
     // ---- biases (virtual-channel order; K's and V's channel 24 carry the constant 1), f16 operand fragments ----
     u32x4 qf[2];
     {
@@ -198,6 +226,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
         vdst[64] = pack8_f16(t + 8);
     }
     __syncthreads();
+    QA_STAMP(3);
 
     // ---- attention of (head, query tile tt) ----
     const int qt = tt;
@@ -262,6 +291,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
         for (int j = 0; j < 8; ++j) p[j] = __builtin_amdgcn_exp2f((ps >> 1) ? s1[8 * (ps & 1) + j] : s0[8 * (ps & 1) + j]);
         t = mfma_f16(vsrc[ps * 64], pack8_f16(p), ps == 0 ? zero16 : t);
     }
+    QA_STAMP(4);
     // ---- normalise (row 24 = register 12 of lane half 0 holds the denominator) and write O as split-bf16 planes ----
     {
         float den, unused;
@@ -283,6 +313,7 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
             *reinterpret_cast<bf16x4*>(ol + 8 * g) = l4;
         }
     }
+    QA_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------

@@ -291,9 +291,14 @@ __device__ __forceinline__ f32x16 attention24(const u32x4* ksrc, const u32x4* vs
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-template <int HID>
+// WS = window side, 8 or 7 (the reference's default, A000_CONFIG.py:55).  A 7x7 window runs on the same 8x8 token grid: the
+// 15 padding tokens (row 7 / column 7) load zeros and store nothing (buffer addressing: an offset beyond the descriptor's
+// range reads 0 and drops the store), and as keys they carry -inf in the packed bias matrix, so their probabilities are 0.
+// The shift seam of the last window row / column sits at WS - WS/2 = 4 for both sizes: the structural masks are unchanged.
+template <int HID, int WS>
 __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args) {
     using G = G24<HID>;
+    static_assert(WS == 7 || WS == 8, "window side");
     __shared__ __attribute__((aligned(16))) char smem[G::l_total];
     u32x4* kimg = reinterpret_cast<u32x4*>(smem + G::l_k);   // [buf][stream][key tile][k-step][lane]
     u32x4* vimg = reinterpret_cast<u32x4*>(smem + G::l_v);   // [buf][stream][pv-step][lane]
@@ -301,9 +306,9 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ws = wave >> 1, qb = wave & 1, r = lane & 31, hf = lane >> 5;
-    const int H = args.H, W = args.W, nwx = W >> 3, nwy = H >> 3, npi = nwx * nwy;
+    const int H = args.H, W = args.W, nwx = W / WS, nwy = H / WS, npi = nwx * nwy;
     const int nwin = args.B * npi;
-    const int sh = args.shift ? 4 : 0;
+    const int sh = args.shift ? WS / 2 : 0;
     const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
 
     for (int i = tid; i < 2 * 2 * 64; i += 256) lvec[i] = reinterpret_cast<const float*>(args.packed[i >> 7] + G::p_vec)[i & 127];
@@ -340,10 +345,12 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
         const int wy = wrem / nwx, wx = wrem - wy * nwx;
         const int buf = it & 1;
         // ---- the lane's token: window row 4qb + (r >> 3), column r & 7; cyclic shift = index arithmetic (a001:442-445) ----
-        int oy = wy * 8 + 4 * qb + (r >> 3) + sh, ox = wx * 8 + (r & 7) + sh;
+        const int ty = 4 * qb + (r >> 3), tx = r & 7;
+        int oy = wy * WS + ty + sh, ox = wx * WS + tx + sh;
         oy = oy >= H ? oy - H : oy;
         ox = ox >= W ? ox - W : ox;
-        const unsigned tokoff = (unsigned)((((b * H + oy) * W + ox) * 24 + 4 * hf) * 4);   // byte offset of the lane's first float4
+        // byte offset of the lane's first float4; padding tokens of a 7x7 window point beyond the buffer (reads 0, stores dropped)
+        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 24 + 4 * hf) * 4) : 0x80000000u;
         // rows 24..31 of every output tile have zero weights: registers 12..15 stay zero
         auto load_rows = [&](f32x16& dstv) {
 #pragma unroll
@@ -510,6 +517,7 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
 struct Pack24Args {
     swf_block_stream_params p[2];
     char* dst[2];
+    int ws;   // window side (7 or 8)
 };
 
 template <int HID>
@@ -584,8 +592,11 @@ __global__ __launch_bounds__(256) void pack24_kernel(Pack24Args a) {
     for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
         const int lane = i & 63, reg = (i >> 6) & 15, kt = (i >> 10) & 1, qb = i >> 11;
         const int key = 32 * kt + rho(reg, lane >> 5), q = 32 * qb + (lane & 31);
-        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7;
-        bm[i] = p.attn.bias_table[(ky - qy + 7) * 15 + (kx - qx + 7)] * kLog2e;
+        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7, ws = a.ws, tw = 2 * ws - 1;
+        float v = 0.f;
+        if (ky >= ws || kx >= ws) v = -INFINITY;   // padding token of a 7x7 window as key: probability 0
+        else if (qy < ws && qx < ws) v = p.attn.bias_table[(ky - qy + ws - 1) * tw + (kx - qx + ws - 1)] * kLog2e;
+        bm[i] = v;
     }
 }
 
@@ -601,8 +612,8 @@ int num_cus24() {
 }  // namespace
 
 bool win24_supported(const swf_block_desc& d) {
-    return d.attn.channels == 24 && d.attn.heads == 8 && d.attn.head_dim == 3 && d.attn.win_h == 8 && d.attn.win_w == 8 &&
-           (d.hidden == 96 || d.hidden == 4);
+    return d.attn.channels == 24 && d.attn.heads == 8 && d.attn.head_dim == 3 && d.attn.win_h == d.attn.win_w &&
+           (d.attn.win_h == 8 || d.attn.win_h == 7) && (d.hidden == 96 || d.hidden == 4);
 }
 
 size_t win24_packed_bytes(const swf_block_desc& d) {
@@ -616,6 +627,7 @@ int pack_win24(const swf_block_desc& d, const swf_block_stream_params& px, const
     Pack24Args a;
     a.p[0] = px; a.p[1] = py;
     a.dst[0] = static_cast<char*>(packed_x); a.dst[1] = static_cast<char*>(packed_y);
+    a.ws = d.attn.win_h;
     if (d.hidden == 96) hipLaunchKernelGGL((pack24_kernel<96>), dim3(32, 2), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((pack24_kernel<4>), dim3(32, 2), dim3(256), 0, stream, a);
     return check_launch("pack_win24");
@@ -624,7 +636,8 @@ int pack_win24(const swf_block_desc& d, const swf_block_stream_params& px, const
 int launch_win24(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,
                  float* x_out, float* y_out, int B, int H, int W, hipStream_t stream, const void* next_packed_x,
                  const void* next_packed_y, size_t next_bytes) {
-    if (!win24_supported(d) || H % 8 || W % 8) return fail(SWF_ERR_UNSUPPORTED, "win24: shape not covered");
+    const int wsd = d.attn.win_h;
+    if (!win24_supported(d) || H % wsd || W % wsd) return fail(SWF_ERR_UNSUPPORTED, "win24: shape not covered");
     if ((int64_t)B * H * W * 24 * 4 >= (int64_t(1) << 31)) return fail(SWF_ERR_UNSUPPORTED, "win24: a stream of %d x %d x %d tokens exceeds the 2 GB buffer window", B, H, W);
     Win24Args a;
     a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
@@ -633,10 +646,15 @@ int launch_win24(const swf_block_desc& d, const void* packed_x, const void* pack
     if (!a.warm[1]) a.warm[0] = nullptr;
     a.warm_bytes = (int)(next_bytes ? next_bytes : win24_packed_bytes(d));
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
-    const int nwin = B * (H / 8) * (W / 8);
+    const int nwin = B * (H / wsd) * (W / wsd);
     const int grid = std::min(nwin, W24_WAVES * num_cus24());   // resident workgroups per CU (register-limited)
-    if (d.hidden == 96) hipLaunchKernelGGL((window24_kernel<96>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((window24_kernel<4>), dim3(grid), dim3(256), 0, stream, a);
+    if (wsd == 8) {
+        if (d.hidden == 96) hipLaunchKernelGGL((window24_kernel<96, 8>), dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((window24_kernel<4, 8>), dim3(grid), dim3(256), 0, stream, a);
+    } else {
+        if (d.hidden == 96) hipLaunchKernelGGL((window24_kernel<96, 7>), dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((window24_kernel<4, 7>), dim3(grid), dim3(256), 0, stream, a);
+    }
     return check_launch("window24");
 }
 

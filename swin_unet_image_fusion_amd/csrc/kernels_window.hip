@@ -1351,7 +1351,9 @@ static bool dims_match(const swf_block_desc& d, int C, int HID) {
 }
 
 bool window_block_supported(const swf_block_desc& d, int B, int H, int W) {
-    if (B <= 0 || H <= 0 || W <= 0 || H % 8 || W % 8) return false;
+    if (B <= 0 || H <= 0 || W <= 0) return false;
+    if (use_win24(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 24 * 4 < (int64_t(1) << 31);
+    if (H % 8 || W % 8) return false;
 #define X(C, HID) if (dims_match(d, C, HID)) return true;
     SWF_WINDOW_SHAPES(X)
 #undef X
