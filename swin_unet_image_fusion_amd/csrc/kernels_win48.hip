@@ -1,0 +1,518 @@
+// Level-1 fused BasicBlock (a005:127-145) for gfx950: C = 48, 8 heads x 6 channels, 8x8 windows, hidden 192 (encoder) or 96
+// (decoder).  The register-resident design of kernels_win24.hip at twice the width: a 256-thread workgroup owns one window,
+// wave w the 32 tokens [32*(w&1), +32) of stream w>>1 for the whole block; activations go from MFMA accumulators to the next
+// MFMA's operand in registers (weights packed with their k columns in accumulator-row order), K / V^T operand fragments are
+// exchanged through lane-linear LDS images, the residual is the C operand of the projection and fc2 MFMAs.
+//
+// What differs from C = 24:
+//  * 48 channels = two 32-row tiles (rows 48..63 are padding); a head's 6 channels + 2 spare rows are one 8-row group, so a
+//    k-step of S^T = K.Q^T holds two WHOLE heads: selecting a head is a compile-time choice of two of the four fragment dwords
+//    (no lane select), its O^T rows are registers 4(h&3).. of BOTH lane halves (channels 0-3 / 4-5, denominator, spare).
+//  * Spare row 6 of a head is the constant 1 in V (softmax denominator), spare row 7 is 1 in K and -max in Q (S - max on the
+//    matrix pipe).  Row 6 of head 0 of the normalised O (= 1) carries the projection bias.
+//  * K = 48 has no spare k slot: the Q/K/V, fc1 and fc2 biases are added in the epilogues (fast-class VALU adds).
+//  * The relative-position bias tile (32 registers) is loaded per window (L2 hit) instead of living in registers for the whole
+//    launch: the MLP phase needs the space.
+//
+// Arithmetic as kernels_win24.hip: linear layers split-bf16 x3 on v_mfma_f32_32x32x16_bf16, Q.K^T and P.V on ..._f16, fp32
+// LayerNorm / softmax / ELU / residual; ELU in exp2 units through v_med3 (fc1 packed with log2 e, fc2 with ln 2).
+#include "kernels_win48.h"
+#include "win_frag.h"
+
+#include <algorithm>
+
+namespace swf {
+namespace {
+
+using namespace wf;
+
+#ifndef W48_WAVES
+#define W48_WAVES 2   // resident workgroups per CU = waves per SIMD
+#endif
+
+template <int HID_>
+struct G48 {
+    static constexpr int C = 48, HID = HID_, HEADS = 8, D = 6;
+    static constexpr int NT1 = HID / 32, KU = HID / 16;
+    static_assert(HID % 32 == 0, "hidden tiles");
+    static constexpr int F_QKV = 0;                   // [q,k,v][tile 2][k-step 3][hi,lo]
+    static constexpr int F_P = 36;                    // [out tile 2][k-step 4][hi,lo]
+    static constexpr int F_W1 = 52;                   // [tile NT1][k-step 3][hi,lo]
+    static constexpr int F_W2 = F_W1 + 6 * NT1;       // [out tile 2][k-step KU][hi,lo]
+    static constexpr int NFRAG = F_W2 + 4 * KU;
+    // fp32 vectors: per lane half [LN1G 24 | LN1B 24 | LN2G 24 | LN2B 24 | B2 24 | BQ 32 | BK 32 | B1 16*NT1], then BV [2 tiles][32]
+    static constexpr int V_LN1G = 0, V_LN1B = 24, V_LN2G = 48, V_LN2B = 72, V_B2 = 96, V_BQ = 120, V_BK = 152, V_B1 = 184, VHF = 288;
+    static_assert(V_B1 + 16 * NT1 <= VHF, "vector block");
+    static constexpr int VSTREAM = 2 * VHF + 64;
+    static constexpr size_t p_vec = size_t(NFRAG) * 1024;
+    static constexpr size_t p_bias = (p_vec + size_t(VSTREAM) * 4 + 15) / 16 * 16;   // fp32 [query block 2][key tile 2][reg/4 4][lane 64][4]
+    static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
+    // LDS: K images [stream 2][key tile 2][vch tile 2][k-step 2] x 1 KB, V^T images [stream 2][vch tile 2][pv-step 4] x 1 KB, vectors
+    static constexpr size_t l_k = 0, l_v = 16 * 1024, l_vec = 32 * 1024, l_total = l_vec + size_t(2) * VSTREAM * 4;
+};
+
+struct Win48Args {
+    const float* in[2];
+    float* out[2];
+    const char* packed[2];
+    const char* warm[2];
+    int B, H, W, shift, cross, warm_bytes;
+};
+
+// LayerNorm (eps 1e-5, biased variance) of the lane's token: 24 of its 48 channels sit in this lane (tile 0 registers 0..15,
+// tile 1 registers 0..7), the other 24 in lane l ^ 32.  Output: the three k-step fragments of the next linear layer.
+__device__ __forceinline__ void layernorm48(const f32x16& x0, const f32x16& x1, const float* vec, int goff, int boff, u32x4 (&xh)[3], u32x4 (&xl)[3]) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) s += x0[i];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) s += x1[i];
+    const float mean = sum_halves(s) * (1.0f / 48.0f);
+    float d[24], q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 24; ++i) {
+        d[i] = (i < 16 ? x0[i] : x1[i - 16]) - mean;
+        q += d[i] * d[i];
+    }
+    const float rstd = __builtin_amdgcn_rsqf(sum_halves(q) * (1.0f / 48.0f) + 1e-5f);
+    float n[24];
+#pragma unroll
+    for (int a = 0; a < 6; ++a) {
+        const float4 g = *reinterpret_cast<const float4*>(vec + goff + 4 * a);
+        const float4 b = *reinterpret_cast<const float4*>(vec + boff + 4 * a);
+        n[4 * a + 0] = d[4 * a + 0] * rstd * g.x + b.x;
+        n[4 * a + 1] = d[4 * a + 1] * rstd * g.y + b.y;
+        n[4 * a + 2] = d[4 * a + 2] * rstd * g.z + b.z;
+        n[4 * a + 3] = d[4 * a + 3] * rstd * g.w + b.w;
+    }
+    split8(n, xh[0], xl[0]);
+    split8(n + 8, xh[1], xl[1]);
+    split8(n + 16, xh[2], xl[2]);
+}
+
+// Attention of one wave: 32 queries x 64 keys x 8 heads.  ksrc / vsrc: the stream's K and V^T operand images in LDS (+ lane);
+// qf[tile][k-step]: the wave's own Q fragments; bias: relative-position bias of (stream, query block); m0 / m1 (MASKED only):
+// this lane's scores of key tile 0 / 1 are masked.  Returns the two O^T tiles: registers 4q..4q+3 of tile T = head 4T+q:
+// lane half 0 channels 0..3, lane half 1 channels 4, 5, the softmax denominator, 0.
+template <bool MASKED>
+__device__ __forceinline__ void attention48(const u32x4* ksrc, const u32x4* vsrc, const u32x4 (&qf)[2][2], const f32x16 (&bias)[2],
+                                            bool half1, bool m0, bool m1, f32x16 (&o)[2]) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    o[0] = zero16;
+    o[1] = zero16;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const int T = h >> 2, hq = h & 3, sp = hq >> 1, sub = hq & 1;
+        // K fragments of (key tile, vch tile T, k-step sp): image index ((kt * 2 + T) * 2 + sp)
+        const u32x4 ka0 = ksrc[((0 * 2 + T) * 2 + sp) * 64], ka1 = ksrc[((1 * 2 + T) * 2 + sp) * 64];
+        // the head's 8 rows are elements 4*sub .. 4*sub+3 of both lane halves: a compile-time choice of two dwords
+        u32x4 qm = {0u, 0u, 0u, 0u};
+        qm[2 * sub] = qf[T][sp][2 * sub];
+        qm[2 * sub + 1] = qf[T][sp][2 * sub + 1];
+        f32x16 s0 = mfma_f16(ka0, qm, bias[0]);   // S^T[key][query] + bias, exp2 units
+        f32x16 s1 = mfma_f16(ka1, qm, bias[1]);
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s0[i] = m0 ? -INFINITY : s0[i];
+                s1[i] = m1 ? -INFINITY : s1[i];
+            }
+        }
+        float mx = max3f(s0[0], s0[1], s1[0]);
+        mx = max3f(mx, s1[1], s0[2]);
+#pragma unroll
+        for (int i = 3; i < 16; i += 2) mx = max3f(mx, s0[i], s0[i + 1 < 16 ? i + 1 : i]);
+#pragma unroll
+        for (int i = 2; i < 16; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+        mx = max_halves(mx);
+        // S - max on the matrix pipe: the head's spare row 7 (lane half 1, element 4*sub+3) is 1 in K and -max (f16) in Q
+        {
+            const f16 nm = (f16)(-mx);
+            qm[2 * sub + 1] |= half1 ? ((unsigned)__builtin_bit_cast(unsigned short, nm) << 16) : 0u;
+            s0 = mfma_f16(ka0, qm, bias[0]);
+            s1 = mfma_f16(ka1, qm, bias[1]);
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) {
+                s0[i] = m0 ? -INFINITY : s0[i];
+                s1[i] = m1 ? -INFINITY : s1[i];
+            }
+        }
+        f32x16 t;
+#pragma unroll
+        for (int ps = 0; ps < 4; ++ps) {
+            float p[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) p[j] = __builtin_amdgcn_exp2f((ps >> 1) ? s1[8 * (ps & 1) + j] : s0[8 * (ps & 1) + j]);
+            const u32x4 pf = pack8_f16(p);
+            const u32x4 va = vsrc[(T * 4 + ps) * 64];
+            t = mfma_f16(va, pf, ps == 0 ? zero16 : t);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[T][4 * hq + j] = t[4 * hq + j];
+        __builtin_amdgcn_sched_barrier(0);   // one head at a time
+    }
+}
+
+template <int HID>
+__global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args) {
+    using G = G48<HID>;
+    __shared__ __attribute__((aligned(16))) char smem[G::l_total];
+    u32x4* kimg = reinterpret_cast<u32x4*>(smem + G::l_k);   // [stream][key tile][vch tile][k-step][lane]
+    u32x4* vimg = reinterpret_cast<u32x4*>(smem + G::l_v);   // [stream][vch tile][pv-step][lane]
+    float* lvec = reinterpret_cast<float*>(smem + G::l_vec);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ws = wave >> 1, qb = wave & 1, r = lane & 31, hf = lane >> 5;
+    const int H = args.H, W = args.W, nwx = W >> 3, nwy = H >> 3, npi = nwx * nwy;
+    const int nwin = args.B * npi;
+    const int sh = args.shift ? 4 : 0;
+    const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
+
+    for (int i = tid; i < 2 * G::VSTREAM; i += 256)
+        lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
+    const int act_bytes = args.B * H * W * 48 * 4;   // < 2^31 (launch_win48)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(args.in[ws])), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, act_bytes, 0x00020000);
+    const unsigned loff = (unsigned)lane * 16u;
+    auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };   // own stream: Q, proj, MLP
+    auto WK = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, loff, f * 1024, 0)); };   // K / V weights
+    const float* vec = lvec + ws * G::VSTREAM + hf * G::VHF;       // own stream, own lane half
+    const float* veck = lvec + kvs * G::VSTREAM + hf * G::VHF;     // K bias: the stream whose weights produce K
+    const float* vecv = lvec + kvs * G::VSTREAM + 2 * G::VHF;      // V bias [tile][32]
+    const bool half1 = hf != 0;
+    const bool col_masked = half1 != (((r >> 2) & 1) != 0);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        SWF_WF_FENCE();
+        const int b = win / npi, wrem = win - b * npi;
+        const int wy = wrem / nwx, wx = wrem - wy * nwx;
+        int oy = wy * 8 + 4 * qb + (r >> 3) + sh, ox = wx * 8 + (r & 7) + sh;
+        oy = oy >= H ? oy - H : oy;
+        ox = ox >= W ? ox - W : ox;
+        const unsigned tokoff = (unsigned)((((b * H + oy) * W + ox) * 48 + 4 * hf) * 4);   // byte offset of the lane's first float4
+        // the lane's 24 channels: tile 0 registers 4a.. = channels 8a+4hf.. (a < 4), tile 1 registers 4a.. = channels 32+8a+4hf.. (a < 2)
+        auto load_rows = [&](f32x16& t0, f32x16& t1) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, tokoff, 32 * a, 0));
+                if (a < 4) { t0[4 * a] = v.x; t0[4 * a + 1] = v.y; t0[4 * a + 2] = v.z; t0[4 * a + 3] = v.w; }
+                else { t1[4 * (a - 4)] = v.x; t1[4 * (a - 4) + 1] = v.y; t1[4 * (a - 4) + 2] = v.z; t1[4 * (a - 4) + 3] = v.w; }
+            }
+#pragma unroll
+            for (int i = 8; i < 16; ++i) t1[i] = 0.f;   // rows 48..63 of every output tile have zero weights: stay zero
+        };
+
+        // ---- LN1, then Q (own stream's weights), K and V (weights of the stream that attends to these tokens) ----
+        u32x4 qf[2][2];
+        {
+            f32x16 x0, x1;
+            load_rows(x0, x1);
+            u32x4 xh[3], xl[3];
+            layernorm48(x0, x1, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+            float t[16];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                SWF_WF_FENCE();
+                f32x16 acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) acc = mma3(WF(G::F_QKV + ((0 * 2 + T) * 3 + s) * 2), WF(G::F_QKV + ((0 * 2 + T) * 3 + s) * 2 + 1), xh[s], xl[s], acc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bq = *reinterpret_cast<const float4*>(vec + G::V_BQ + 16 * T + 4 * g);
+                    t[4 * g] = acc[4 * g] + bq.x; t[4 * g + 1] = acc[4 * g + 1] + bq.y; t[4 * g + 2] = acc[4 * g + 2] + bq.z; t[4 * g + 3] = acc[4 * g + 3] + bq.w;
+                }
+                qf[T][0] = pack8_f16(t);
+                qf[T][1] = pack8_f16(t + 8);
+            }
+            if (win != (int)blockIdx.x) __syncthreads();   // the attention phase of the window before has read the images
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                SWF_WF_FENCE();
+                f32x16 acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) acc = mma3(WK(G::F_QKV + ((1 * 2 + T) * 3 + s) * 2), WK(G::F_QKV + ((1 * 2 + T) * 3 + s) * 2 + 1), xh[s], xl[s], acc);
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 bk = *reinterpret_cast<const float4*>(veck + G::V_BK + 16 * T + 4 * g);
+                    t[4 * g] = acc[4 * g] + bk.x; t[4 * g + 1] = acc[4 * g + 1] + bk.y; t[4 * g + 2] = acc[4 * g + 2] + bk.z; t[4 * g + 3] = acc[4 * g + 3] + bk.w;
+                }
+                u32x4* kdst = kimg + (((kvs * 2 + qb) * 2 + T) * 2) * 64 + lane;
+                kdst[0] = pack8_f16(t);
+                kdst[64] = pack8_f16(t + 8);
+            }
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {   // V: tokens in rows (A = x fragments, B = weight fragments)
+                SWF_WF_FENCE();
+                f32x16 acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) acc = mma3(xh[s], xl[s], WK(G::F_QKV + ((2 * 2 + T) * 3 + s) * 2), WK(G::F_QKV + ((2 * 2 + T) * 3 + s) * 2 + 1), acc);
+                const float bv = vecv[32 * T + r];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = acc[i] + bv;
+                u32x4* vdst = vimg + ((kvs * 2 + T) * 4 + 2 * qb) * 64 + lane;
+                vdst[0] = pack8_f16(t);
+                vdst[64] = pack8_f16(t + 8);
+            }
+        }
+        __syncthreads();   // K / V^T images of both streams complete
+
+        // ---- attention of the wave's 32 queries, 8 heads (shift mask: kernels_win24.hip) ----
+        f32x16 o[2];
+        {
+            f32x16 bias[2];
+            {
+                const __amdgpu_buffer_rsrc_t& brs = wrs;
+#pragma unroll
+                for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                    for (int a = 0; a < 4; ++a) {
+                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, loff, (int)G::p_bias + ((qb * 2 + kt) * 4 + a) * 1024, 0));
+                        bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
+                    }
+            }
+            const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
+            const u32x4* ksrc = kimg + (ws * 8) * 64 + lane;
+            const u32x4* vsrc = vimg + (ws * 8) * 64 + lane;
+            if (rowv || colv) {
+                const bool m0 = (rowv && qb == 1) || (colv && col_masked), m1 = (rowv && qb == 0) || (colv && col_masked);
+                attention48<true>(ksrc, vsrc, qf, bias, half1, m0, m1, o);
+            } else {
+                attention48<false>(ksrc, vsrc, qf, bias, half1, false, false, o);
+            }
+        }
+
+        // ---- normalise (denominator: lane half 1, register 4q+2), output projection + bias + residual ----
+        f32x16 res0, res1;
+        SWF_WF_FENCE();
+        load_rows(res0, res1);
+        {
+            u32x4 oh[4], ol[4];
+#pragma unroll
+            for (int T = 0; T < 2; ++T) {
+                float t[16];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float lo_, den;
+                    halves(o[T][4 * q + 2], lo_, den);   // den = the value of lanes 32..63
+                    const float inv = __builtin_amdgcn_rcpf(den);
+                    // lane half 1: register 4q+2 becomes den / den = 1 (the projection bias rides on head 0's), 4q+3 stays 0
+                    t[4 * q] = o[T][4 * q] * inv; t[4 * q + 1] = o[T][4 * q + 1] * inv; t[4 * q + 2] = o[T][4 * q + 2] * inv; t[4 * q + 3] = o[T][4 * q + 3] * inv;
+                }
+                split8(t, oh[2 * T], ol[2 * T]);
+                split8(t + 8, oh[2 * T + 1], ol[2 * T + 1]);
+            }
+            SWF_WF_FENCE();
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks) {
+                res0 = mma3(WF(G::F_P + (0 * 4 + ks) * 2), WF(G::F_P + (0 * 4 + ks) * 2 + 1), oh[ks], ol[ks], res0);
+                res1 = mma3(WF(G::F_P + (1 * 4 + ks) * 2), WF(G::F_P + (1 * 4 + ks) * 2 + 1), oh[ks], ol[ks], res1);
+            }
+        }
+
+        // ---- LN2, MLP: fc1 tile -> ELU -> split -> two k-steps of fc2 accumulating onto the residual ----
+        {
+            u32x4 xh[3], xl[3];
+            layernorm48(res0, res1, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+#pragma unroll
+            for (int tI = 0; tI < G::NT1; ++tI) {
+                SWF_WF_FENCE();
+                f32x16 acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) acc = mma3(WF(G::F_W1 + (tI * 3 + s) * 2), WF(G::F_W1 + (tI * 3 + s) * 2 + 1), xh[s], xl[s], acc);
+                float e[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b1 = *reinterpret_cast<const float4*>(vec + G::V_B1 + 16 * tI + 4 * g);
+                    const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {   // ELU in exp2 units: median of (u, log2 e (2^u - 1), 0)
+                        const float u = acc[4 * g + j] + bb[j];
+                        const float L = __builtin_fmaf(__builtin_amdgcn_exp2f(u), kLog2e, -kLog2e);
+                        e[4 * g + j] = __builtin_amdgcn_fmed3f(u, L, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 hh, hl;
+                    split8(e + 8 * s2, hh, hl);
+                    SWF_WF_FENCE();
+                    const int u = 2 * tI + s2;
+                    res0 = mma3(WF(G::F_W2 + (0 * G::KU + u) * 2), WF(G::F_W2 + (0 * G::KU + u) * 2 + 1), hh, hl, res0);
+                    res1 = mma3(WF(G::F_W2 + (1 * G::KU + u) * 2), WF(G::F_W2 + (1 * G::KU + u) * 2 + 1), hh, hl, res1);
+                }
+                __builtin_amdgcn_sched_barrier(0);   // one hidden tile at a time
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const float4 b2 = *reinterpret_cast<const float4*>(vec + G::V_B2 + 4 * a);
+                if (a < 4) { res0[4 * a] += b2.x; res0[4 * a + 1] += b2.y; res0[4 * a + 2] += b2.z; res0[4 * a + 3] += b2.w; }
+                else { res1[4 * (a - 4)] += b2.x; res1[4 * (a - 4) + 1] += b2.y; res1[4 * (a - 4) + 2] += b2.z; res1[4 * (a - 4) + 3] += b2.w; }
+            }
+        }
+
+        // ---- store the own rows (un-shift = the same index map) ----
+#pragma unroll
+        for (int a = 0; a < 6; ++a) {
+            const f32x4 v = a < 4 ? f32x4{res0[4 * a], res0[4 * a + 1], res0[4 * a + 2], res0[4 * a + 3]}
+                                  : f32x4{res1[4 * (a - 4)], res1[4 * (a - 4) + 1], res1[4 * (a - 4) + 2], res1[4 * (a - 4) + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, tokoff, 32 * a, 0);
+        }
+    }
+
+    // ---- L2 warm-up of the next block's packed weights (see kernels_window.hip) ----
+    if (args.warm[0]) {
+        const int nsl = max(1, (int)gridDim.x / 8), sl = ((int)blockIdx.x / 8) % nsl;
+        const int lines = (args.warm_bytes + 127) / 128;
+        const int per = (lines + nsl - 1) / nsl, l0 = sl * per, l1 = min(lines, l0 + per);
+        unsigned acc = 0;
+        for (int s2 = 0; s2 < 2; ++s2)
+            for (int l = l0 + tid; l < l1; l += 256) acc ^= *reinterpret_cast<const unsigned*>(args.warm[s2] + (size_t)l * 128);
+        if (acc == 0x9e3779b9u && args.B < 0) args.out[0][0] = 0.f;   // never true: keeps the loads alive
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct Pack48Args {
+    swf_block_stream_params p[2];
+    char* dst[2];
+};
+
+// k index (input channel / virtual channel / hidden unit offset) of element e of k-step s in lane half hf, for an operand
+// produced as accumulator tiles: step s covers registers 8(s&1).. of tile s>>1
+__host__ __device__ constexpr int kslot(int s, int hf, int e) { return 32 * (s >> 1) + rho(8 * (s & 1) + e, hf); }
+
+template <int HID>
+__global__ __launch_bounds__(256) void pack48_kernel(Pack48Args a) {
+    using G = G48<HID>;
+    const int st = blockIdx.y;
+    const swf_block_stream_params& p = a.p[st];
+    char* dst = a.dst[st];
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    const float qscale = kLog2e / sqrtf(6.0f);   // d^-0.5 (a001:32-34) and exp -> exp2
+    auto bia = [](const swf_linear& l, int n) { return l.bias ? l.bias[n] : 0.f; };
+
+    for (int idx = gtid; idx < G::NFRAG * 512; idx += gsz) {
+        const int f = idx >> 9, lane = (idx >> 3) & 63, e = idx & 7, r = lane & 31, hf = lane >> 5;
+        float val = 0.f;
+        int hl;
+        if (f < G::F_P) {   // Q / K / V: row (A) or column (B) = virtual channel 32T + r = 8 * head + c; k = input channel in accumulator order
+            hl = f & 1;
+            const int g = f >> 1, s = g % 3, T = (g / 3) & 1, m = g / 6;
+            const int k = kslot(s, hf, e), head = 4 * T + (r >> 3), c = r & 7;
+            const swf_linear& l = m == 0 ? p.attn.q : m == 1 ? p.attn.k : p.attn.v;
+            if (c < 6 && k < 48) {
+                val = l.weight[(head * 6 + c) * 48 + k];
+                if (m == 0) val *= qscale;
+            }
+        } else if (f < G::F_W1) {   // projection: row = output channel 32To + r; k = virtual channel of O, head 0's row 6 (= 1) carries the bias
+            const int g = (f - G::F_P) >> 1, ks = g & 3, To = g >> 2;
+            hl = f & 1;
+            const int n = 32 * To + r, v = kslot(ks, hf, e), head = v >> 3, c = v & 7;
+            if (n < 48) val = c < 6 ? p.attn.proj.weight[n * 48 + head * 6 + c] : (v == 6 ? bia(p.attn.proj, n) : 0.f);
+        } else if (f < G::F_W2) {   // fc1 (exp2 units): row = hidden unit
+            const int g = (f - G::F_W1) >> 1, s = g % 3, tI = g / 3;
+            hl = f & 1;
+            const int k = kslot(s, hf, e), hid = 32 * tI + r;
+            if (k < 48) val = p.fc1.weight[hid * 48 + k] * kLog2e;
+        } else {   // fc2 (x ln 2): row = output channel; k = hidden unit in accumulator order
+            const int g = (f - G::F_W2) >> 1, u = g % G::KU, To = g / G::KU;
+            hl = f & 1;
+            const int n = 32 * To + r, hid = kslot(u, hf, e);
+            if (n < 48) val = p.fc2.weight[n * HID + hid] * kLn2;
+        }
+        const bf16 hi = (bf16)val;
+        reinterpret_cast<bf16*>(dst)[idx] = hl ? (bf16)(val - (float)hi) : hi;
+    }
+    float* vec = reinterpret_cast<float*>(dst + G::p_vec);
+    for (int i = gtid; i < G::VSTREAM; i += gsz) {
+        float v = 0.f;
+        if (i < 2 * G::VHF) {
+            const int hf = i / G::VHF, j = i % G::VHF;
+            if (j < G::V_BQ) {   // 24-channel vectors: entry k = register index (tile 0: 0..15, tile 1: 16..23)
+                const int which = j / 24, k = j % 24;
+                const int c = k < 16 ? rho(k, hf) : 32 + rho(k - 16, hf);
+                v = which == 0 ? p.ln1.gamma[c] : which == 1 ? p.ln1.beta[c] : which == 2 ? p.ln2.gamma[c] : which == 3 ? p.ln2.beta[c] : bia(p.fc2, c);
+            } else if (j < G::V_B1) {   // Q / K bias in accumulator order; K's spare row 7 is the constant 1
+                const int isk = j >= G::V_BK, k = (j - (isk ? G::V_BK : G::V_BQ)), T = k >> 4, vch = 32 * T + rho(k & 15, hf);
+                const int head = vch >> 3, c = vch & 7;
+                if (c < 6) v = isk ? bia(p.attn.k, head * 6 + c) : bia(p.attn.q, head * 6 + c) * qscale;
+                else if (isk && c == 7) v = 1.0f;
+            } else if (j < G::V_B1 + 16 * G::NT1) {
+                const int k = j - G::V_B1, hid = 32 * (k >> 4) + rho(k & 15, hf);
+                v = bia(p.fc1, hid) * kLog2e;
+            }
+        } else {   // V bias by virtual channel; spare row 6 is the constant 1 (softmax denominator)
+            const int vch = i - 2 * G::VHF, head = vch >> 3, c = vch & 7;
+            v = c < 6 ? bia(p.attn.v, head * 6 + c) : (c == 6 ? 1.0f : 0.f);
+        }
+        vec[i] = v;
+    }
+    // relative-position bias (a001:113-144), exp2 units: [query block][key tile][register / 4][lane][register % 4]
+    float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
+        const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, kt = (i >> 10) & 1, qb = i >> 11;
+        const int key = 32 * kt + rho(4 * a4 + j, lane >> 5), q = 32 * qb + (lane & 31);
+        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7;
+        bm[i] = p.attn.bias_table[(ky - qy + 7) * 15 + (kx - qx + 7)] * kLog2e;
+    }
+}
+
+int num_cus48() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+}  // namespace
+
+bool win48_supported(const swf_block_desc& d) {
+    return d.attn.channels == 48 && d.attn.heads == 8 && d.attn.head_dim == 6 && d.attn.win_h == 8 && d.attn.win_w == 8 &&
+           (d.hidden == 192 || d.hidden == 96);
+}
+
+size_t win48_packed_bytes(const swf_block_desc& d) {
+    if (!win48_supported(d)) return 0;
+    return align_up(d.hidden == 192 ? G48<192>::p_total : G48<96>::p_total, 256);
+}
+
+int pack_win48(const swf_block_desc& d, const swf_block_stream_params& px, const swf_block_stream_params& py, void* packed_x,
+               void* packed_y, hipStream_t stream) {
+    if (!win48_supported(d)) return fail(SWF_ERR_UNSUPPORTED, "pack_win48: shape not covered");
+    Pack48Args a;
+    a.p[0] = px; a.p[1] = py;
+    a.dst[0] = static_cast<char*>(packed_x); a.dst[1] = static_cast<char*>(packed_y);
+    if (d.hidden == 192) hipLaunchKernelGGL((pack48_kernel<192>), dim3(64, 2), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((pack48_kernel<96>), dim3(64, 2), dim3(256), 0, stream, a);
+    return check_launch("pack_win48");
+}
+
+int launch_win48(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,
+                 float* x_out, float* y_out, int B, int H, int W, hipStream_t stream, const void* next_packed_x,
+                 const void* next_packed_y, size_t next_bytes) {
+    if (!win48_supported(d) || H % 8 || W % 8) return fail(SWF_ERR_UNSUPPORTED, "win48: shape not covered");
+    if ((int64_t)B * H * W * 48 * 4 >= (int64_t(1) << 31)) return fail(SWF_ERR_UNSUPPORTED, "win48: a stream of %d x %d x %d tokens exceeds the 2 GB buffer window", B, H, W);
+    Win48Args a;
+    a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
+    a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
+    a.warm[0] = static_cast<const char*>(next_packed_x); a.warm[1] = static_cast<const char*>(next_packed_y);
+    if (!a.warm[1]) a.warm[0] = nullptr;
+    a.warm_bytes = (int)(next_bytes ? next_bytes : win48_packed_bytes(d));
+    a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
+    const int nwin = B * (H / 8) * (W / 8);
+    const int grid = std::min(nwin, W48_WAVES * num_cus48());
+    if (d.hidden == 192) hipLaunchKernelGGL((window48_kernel<192>), dim3(grid), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((window48_kernel<96>), dim3(grid), dim3(256), 0, stream, a);
+    return check_launch("window48");
+}
+
+}  // namespace swf

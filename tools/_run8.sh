@@ -1,5 +1,5 @@
 cd $GRAFT_REPO_ROOT
-for v in "" swin_unet_image_fusion_amd/libswf_w4.so; do
+for v in "" swin_unet_image_fusion_amd/libswf_w2.so; do
   echo "=== lib: ${v:-default}"
   if [ -n "$v" ]; then export SWF_LIB_PATH=$PWD/$v; else unset SWF_LIB_PATH; fi
   python - <<'PY'
