@@ -207,11 +207,9 @@ __device__ __forceinline__ void layernorm_frags(const f32x16& res, const float* 
 
 // Attention of one wave: 32 queries x 64 keys x 8 heads.  ksrc / vsrc: the stream's K and V^T operand images in LDS (+ lane);
 // qf: the wave's own Q fragments; bias: relative-position bias of (stream, query block), C operand of the S^T MFMAs;
-// m0 / m1 (MASKED only): this lane's scores of key tile 0 / 1 are masked.  Returns the O^T accumulator: registers 4a..4a+3 of
+// (with -inf where the shift mask applies).  Returns the O^T accumulator: registers 4a..4a+3 of
 // lane half p = channels 0..2 and softmax denominator of head 2a + p.
-template <bool MASKED>
-__device__ __forceinline__ f32x16 attention24(const u32x4* ksrc, const u32x4* vsrc, const u32x4 (&qf)[2], const f32x16 (&bias)[2],
-                                              bool half1, bool m0, bool m1) {
+__device__ __forceinline__ f32x16 attention24(const u32x4* ksrc, const u32x4* vsrc, const u32x4 (&qf)[2], const f32x16 (&bias)[2], bool half1) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     f32x16 o = zero16;
     // Register budget (three, ideally four waves per SIMD): the K / V^T fragments are read from LDS where they are used
@@ -232,13 +230,6 @@ __device__ __forceinline__ f32x16 attention24(const u32x4* ksrc, const u32x4* vs
             s0 = mfma_f16(ka0, qm, bias[0]);   // S^T[key][query] + bias, exp2 units
             s1 = mfma_f16(ka1, qm, bias[1]);
         }
-        if constexpr (MASKED) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s0[i] = m0 ? -INFINITY : s0[i];
-                s1[i] = m1 ? -INFINITY : s1[i];
-            }
-        }
         float mx = max3f(s0[0], s0[1], s1[0]);
         mx = max3f(mx, s1[1], s0[2]);
 #pragma unroll
@@ -258,13 +249,6 @@ __device__ __forceinline__ f32x16 attention24(const u32x4* ksrc, const u32x4* vs
             qm[2 * sub + 1] = (keep ? qf[s][2 * sub + 1] : 0u) | (nmb << 16);
             s0 = mfma_f16(ka0, qm, bias[0]);
             s1 = mfma_f16(ka1, qm, bias[1]);
-            if constexpr (MASKED) {
-#pragma unroll
-                for (int i = 0; i < 16; ++i) {
-                    s0[i] = m0 ? -INFINITY : s0[i];
-                    s1[i] = m1 ? -INFINITY : s1[i];
-                }
-            }
         } else {
 #pragma unroll
             for (int i = 0; i < 16; ++i) { s0[i] -= mx; s1[i] -= mx; }
@@ -327,13 +311,16 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
     const float* vec = lvec + (ws * 2 + hf) * 64;
     // relative-position bias of (stream, query block), both key tiles: C operand of the S^T MFMAs for the whole launch
     f32x16 bias[2];
-    {
-        const float* bm = reinterpret_cast<const float*>(args.packed[ws] + G::p_bias) + qb * 2 * 16 * 64 + lane;
+    // resident bias tile of this wave's token half; wave-uniform base (qb) in the scalar offset, lane in the vector offset
+    const int boff = __builtin_amdgcn_readfirstlane((int)G::p_bias + qb * 2 * 16 * 64 * 4);
+    auto load_bias = [&]() {
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bias[kt][i] = bm[(kt * 16 + i) * 64];
-    }
+            for (int i = 0; i < 16; ++i)
+                bias[kt][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, boff + (kt * 16 + i) * 256, 0));
+    };
+    load_bias();
     const bool half1 = hf != 0;
     const bool col_masked = half1 != (((r >> 2) & 1) != 0);   // last-window-column variant: this lane's keys lie across the seam
     __syncthreads();
@@ -408,20 +395,22 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
         // only the windows of the last window row / column of a shifted block hold two region labels, split at row /
         // column 4 of the window.  In the S^T layout "query and key on different sides of the row seam" is a whole key tile
         // (key tile kt holds window rows 4kt..4kt+3, the wave's queries rows 4qb..4qb+3) and "different sides of the column
-        // seam" is a whole lane (lane half hf holds key columns 4hf..4hf+3, the lane's query column is r & 7).  The masked
-        // variant is a separate instantiation: a wave-uniform branch around it instead of branches inside the head loop
-        // (those cost 60 registers of live-range extension).
+        // seam" is a whole lane (lane half hf holds key columns 4hf..4hf+3, the lane's query column is r & 7).  So the mask
+        // is -inf added to a whole bias tile (the C operand of the S^T MFMAs) once per edge window — a wave-uniform branch, no
+        // work inside the head loop — and the resident bias registers are read again (L2 hit) after such a window.
         f32x16 o;
         {
             const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
             const u32x4* ksrc = kimg + ((buf * 2 + ws) * 4) * 64 + lane;
             const u32x4* vsrc = vimg + ((buf * 2 + ws) * 4) * 64 + lane;
             if (rowv || colv) {
-                const bool m0 = (rowv && qb == 1) || (colv && col_masked), m1 = (rowv && qb == 0) || (colv && col_masked);
-                o = attention24<true>(ksrc, vsrc, qf, bias, half1, m0, m1);
-            } else {
-                o = attention24<false>(ksrc, vsrc, qf, bias, half1, false, false);
+                const float pen0 = ((rowv && qb == 1) || (colv && col_masked)) ? -INFINITY : 0.f;
+                const float pen1 = ((rowv && qb == 0) || (colv && col_masked)) ? -INFINITY : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { bias[0][i] += pen0; bias[1][i] += pen1; }
             }
+            o = attention24(ksrc, vsrc, qf, bias, half1);
+            if (rowv || colv) load_bias();
         }
 
         // ---- normalise, output projection + bias + residual: res is the C operand ----

@@ -91,12 +91,11 @@ __device__ __forceinline__ void layernorm48(const f32x16& x0, const f32x16& x1, 
 }
 
 // Attention of one wave: 32 queries x 64 keys x 8 heads.  ksrc / vsrc: the stream's K and V^T operand images in LDS (+ lane);
-// qf[tile][k-step]: the wave's own Q fragments; bias: relative-position bias of (stream, query block); m0 / m1 (MASKED only):
-// this lane's scores of key tile 0 / 1 are masked.  Returns the two O^T tiles: registers 4q..4q+3 of tile T = head 4T+q:
+// qf[tile][k-step]: the wave's own Q fragments; bias: relative-position bias of (stream, query block), with -inf where the shift
+// mask applies (the reference assigns -1e10 to those scores: probability exactly 0).  Returns the two O^T tiles: registers 4q..4q+3 of tile T = head 4T+q:
 // lane half 0 channels 0..3, lane half 1 channels 4, 5, the softmax denominator, 0.
-template <bool MASKED>
 __device__ __forceinline__ void attention48(const u32x4* ksrc, const u32x4* vsrc, const u32x4 (&qf)[2][2], const f32x16 (&bias)[2],
-                                            bool half1, bool m0, bool m1, f32x16 (&o)[2]) {
+                                            bool half1, f32x16 (&o)[2]) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     o[0] = zero16;
     o[1] = zero16;
@@ -109,46 +108,41 @@ __device__ __forceinline__ void attention48(const u32x4* ksrc, const u32x4* vsrc
         u32x4 qm = {0u, 0u, 0u, 0u};
         qm[2 * sub] = qf[T][sp][2 * sub];
         qm[2 * sub + 1] = qf[T][sp][2 * sub + 1];
-        f32x16 s0 = mfma_f16(ka0, qm, bias[0]);   // S^T[key][query] + bias, exp2 units
-        f32x16 s1 = mfma_f16(ka1, qm, bias[1]);
-        if constexpr (MASKED) {
+        // Pass 1: the row maximum, one key tile at a time (16 live score registers instead of 32).  S^T[key][query] + bias, exp2 units.
+        float mx;
+        {
+            f32x16 s0 = mfma_f16(ka0, qm, bias[0]);
+            mx = max3f(s0[0], s0[1], s0[2]);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s0[i] = m0 ? -INFINITY : s0[i];
-                s1[i] = m1 ? -INFINITY : s1[i];
-            }
+            for (int i = 3; i < 15; i += 2) mx = max3f(mx, s0[i], s0[i + 1]);
+            mx = __builtin_fmaxf(mx, s0[15]);
         }
-        float mx = max3f(s0[0], s0[1], s1[0]);
-        mx = max3f(mx, s1[1], s0[2]);
+        {
+            f32x16 s1 = mfma_f16(ka1, qm, bias[1]);
 #pragma unroll
-        for (int i = 3; i < 16; i += 2) mx = max3f(mx, s0[i], s0[i + 1 < 16 ? i + 1 : i]);
-#pragma unroll
-        for (int i = 2; i < 16; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+            for (int i = 0; i < 16; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+        }
         mx = max_halves(mx);
-        // S - max on the matrix pipe: the head's spare row 7 (lane half 1, element 4*sub+3) is 1 in K and -max (f16) in Q
+        // Pass 2: S - max on the matrix pipe — the head's spare row 7 (lane half 1, element 4*sub+3) is 1 in K and -max (f16)
+        // in Q — then P = exp2(.) in f16 and O^T += V^T . P^T, again one key tile (two pv-steps of 16 keys) at a time
         {
             const f16 nm = (f16)(-mx);
             qm[2 * sub + 1] |= half1 ? ((unsigned)__builtin_bit_cast(unsigned short, nm) << 16) : 0u;
-            s0 = mfma_f16(ka0, qm, bias[0]);
-            s1 = mfma_f16(ka1, qm, bias[1]);
-        }
-        if constexpr (MASKED) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) {
-                s0[i] = m0 ? -INFINITY : s0[i];
-                s1[i] = m1 ? -INFINITY : s1[i];
-            }
         }
         f32x16 t;
 #pragma unroll
-        for (int ps = 0; ps < 4; ++ps) {
-            float p[8];
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 sc = mfma_f16(kt ? ka1 : ka0, qm, bias[kt]);
 #pragma unroll
-            for (int j = 0; j < 8; ++j) p[j] = __builtin_amdgcn_exp2f((ps >> 1) ? s1[8 * (ps & 1) + j] : s0[8 * (ps & 1) + j]);
-            const u32x4 pf = pack8_f16(p);
-            const u32x4 va = vsrc[(T * 4 + ps) * 64];
-            t = mfma_f16(va, pf, ps == 0 ? zero16 : t);
-            __builtin_amdgcn_sched_barrier(0);
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j] = __builtin_amdgcn_exp2f(sc[8 * s2 + j]);
+                const u32x4 pf = pack8_f16(p);
+                const u32x4 va = vsrc[(T * 4 + 2 * kt + s2) * 64];
+                t = mfma_f16(va, pf, (kt == 0 && s2 == 0) ? zero16 : t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[T][4 * hq + j] = t[4 * hq + j];
@@ -212,53 +206,57 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
         // ---- LN1, then Q (own stream's weights), K and V (weights of the stream that attends to these tokens) ----
         u32x4 qf[2][2];
         {
+            // Six tile phases (Q0 Q1 K0 K1 V0 V1), 6 weight fragments each.  With two waves per SIMD nothing else hides an L2 round
+            // trip, so the fragments of phase p+1 are requested before the MFMAs of phase p (double register set; the fences pin
+            // the issue points, the in-order vmcnt lets phase p's data be waited for while phase p+1's stays in flight).
+            u32x4 wq[2][6];
+            auto req = [&](int ph, u32x4 (&dst)[6]) {
+                const int m = ph >> 1, T = ph & 1;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dst[i] = m == 0 ? WF(G::F_QKV + ((m * 2 + T) * 3) * 2 + i) : WK(G::F_QKV + ((m * 2 + T) * 3) * 2 + i);
+            };
+            req(0, wq[0]);
             f32x16 x0, x1;
             load_rows(x0, x1);
             u32x4 xh[3], xl[3];
             layernorm48(x0, x1, vec, G::V_LN1G, G::V_LN1B, xh, xl);
             float t[16];
 #pragma unroll
-            for (int T = 0; T < 2; ++T) {
+            for (int ph = 0; ph < 6; ++ph) {
+                const int m = ph >> 1, T = ph & 1;
                 SWF_WF_FENCE();
+                if (ph + 1 < 6) req(ph + 1, wq[(ph + 1) & 1]);
+                SWF_WF_FENCE();
+                const u32x4 (&w)[6] = wq[ph & 1];
                 f32x16 acc = zero16;
+                if (m < 2) {
 #pragma unroll
-                for (int s = 0; s < 3; ++s) acc = mma3(WF(G::F_QKV + ((0 * 2 + T) * 3 + s) * 2), WF(G::F_QKV + ((0 * 2 + T) * 3 + s) * 2 + 1), xh[s], xl[s], acc);
+                    for (int s = 0; s < 3; ++s) acc = mma3(w[2 * s], w[2 * s + 1], xh[s], xl[s], acc);   // [virtual channel][token]
+                    const float* bsrc = m == 0 ? vec + G::V_BQ : veck + G::V_BK;
 #pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bq = *reinterpret_cast<const float4*>(vec + G::V_BQ + 16 * T + 4 * g);
-                    t[4 * g] = acc[4 * g] + bq.x; t[4 * g + 1] = acc[4 * g + 1] + bq.y; t[4 * g + 2] = acc[4 * g + 2] + bq.z; t[4 * g + 3] = acc[4 * g + 3] + bq.w;
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 bb = *reinterpret_cast<const float4*>(bsrc + 16 * T + 4 * g);
+                        t[4 * g] = acc[4 * g] + bb.x; t[4 * g + 1] = acc[4 * g + 1] + bb.y; t[4 * g + 2] = acc[4 * g + 2] + bb.z; t[4 * g + 3] = acc[4 * g + 3] + bb.w;
+                    }
+                    if (m == 0) {
+                        qf[T][0] = pack8_f16(t);
+                        qf[T][1] = pack8_f16(t + 8);
+                    } else {
+                        if (T == 0 && win != (int)blockIdx.x) __syncthreads();   // the attention phase of the window before has read the images
+                        u32x4* kdst = kimg + (((kvs * 2 + qb) * 2 + T) * 2) * 64 + lane;
+                        kdst[0] = pack8_f16(t);
+                        kdst[64] = pack8_f16(t + 8);
+                    }
+                } else {   // V: tokens in rows (A = x fragments, B = weight fragments)
+#pragma unroll
+                    for (int s = 0; s < 3; ++s) acc = mma3(xh[s], xl[s], w[2 * s], w[2 * s + 1], acc);
+                    const float bv = vecv[32 * T + r];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) t[i] = acc[i] + bv;
+                    u32x4* vdst = vimg + ((kvs * 2 + T) * 4 + 2 * qb) * 64 + lane;
+                    vdst[0] = pack8_f16(t);
+                    vdst[64] = pack8_f16(t + 8);
                 }
-                qf[T][0] = pack8_f16(t);
-                qf[T][1] = pack8_f16(t + 8);
-            }
-            if (win != (int)blockIdx.x) __syncthreads();   // the attention phase of the window before has read the images
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {
-                SWF_WF_FENCE();
-                f32x16 acc = zero16;
-#pragma unroll
-                for (int s = 0; s < 3; ++s) acc = mma3(WK(G::F_QKV + ((1 * 2 + T) * 3 + s) * 2), WK(G::F_QKV + ((1 * 2 + T) * 3 + s) * 2 + 1), xh[s], xl[s], acc);
-#pragma unroll
-                for (int g = 0; g < 4; ++g) {
-                    const float4 bk = *reinterpret_cast<const float4*>(veck + G::V_BK + 16 * T + 4 * g);
-                    t[4 * g] = acc[4 * g] + bk.x; t[4 * g + 1] = acc[4 * g + 1] + bk.y; t[4 * g + 2] = acc[4 * g + 2] + bk.z; t[4 * g + 3] = acc[4 * g + 3] + bk.w;
-                }
-                u32x4* kdst = kimg + (((kvs * 2 + qb) * 2 + T) * 2) * 64 + lane;
-                kdst[0] = pack8_f16(t);
-                kdst[64] = pack8_f16(t + 8);
-            }
-#pragma unroll
-            for (int T = 0; T < 2; ++T) {   // V: tokens in rows (A = x fragments, B = weight fragments)
-                SWF_WF_FENCE();
-                f32x16 acc = zero16;
-#pragma unroll
-                for (int s = 0; s < 3; ++s) acc = mma3(xh[s], xl[s], WK(G::F_QKV + ((2 * 2 + T) * 3 + s) * 2), WK(G::F_QKV + ((2 * 2 + T) * 3 + s) * 2 + 1), acc);
-                const float bv = vecv[32 * T + r];
-#pragma unroll
-                for (int i = 0; i < 16; ++i) t[i] = acc[i] + bv;
-                u32x4* vdst = vimg + ((kvs * 2 + T) * 4 + 2 * qb) * 64 + lane;
-                vdst[0] = pack8_f16(t);
-                vdst[64] = pack8_f16(t + 8);
             }
         }
         __syncthreads();   // K / V^T images of both streams complete
@@ -280,12 +278,13 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
             const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
             const u32x4* ksrc = kimg + (ws * 8) * 64 + lane;
             const u32x4* vsrc = vimg + (ws * 8) * 64 + lane;
-            if (rowv || colv) {
-                const bool m0 = (rowv && qb == 1) || (colv && col_masked), m1 = (rowv && qb == 0) || (colv && col_masked);
-                attention48<true>(ksrc, vsrc, qf, bias, half1, m0, m1, o);
-            } else {
-                attention48<false>(ksrc, vsrc, qf, bias, half1, false, false, o);
+            if (rowv || colv) {   // wave-uniform: the mask is a whole key tile / a whole lane, folded into the C operand once per window
+                const float pen0 = ((rowv && qb == 1) || (colv && col_masked)) ? -INFINITY : 0.f;
+                const float pen1 = ((rowv && qb == 0) || (colv && col_masked)) ? -INFINITY : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { bias[0][i] += pen0; bias[1][i] += pen1; }
             }
+            attention48(ksrc, vsrc, qf, bias, half1, o);
         }
 
         // ---- normalise (denominator: lane half 1, register 4q+2), output projection + bias + residual ----
@@ -318,14 +317,32 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
 
         // ---- LN2, MLP: fc1 tile -> ELU -> split -> two k-steps of fc2 accumulating onto the residual ----
         {
+            // fc1 fragments of tile tI+1 and the fc2 fragments of tile tI are requested at the top of tile tI (see the Q/K/V phases)
+            u32x4 w1[2][6];
+            auto req1 = [&](int tI, u32x4 (&dst)[6]) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dst[i] = WF(G::F_W1 + tI * 6 + i);
+            };
+            req1(0, w1[0]);
             u32x4 xh[3], xl[3];
             layernorm48(res0, res1, vec, G::V_LN2G, G::V_LN2B, xh, xl);
 #pragma unroll
             for (int tI = 0; tI < G::NT1; ++tI) {
                 SWF_WF_FENCE();
+                u32x4 w2[2][2][2];   // [out tile][k-step of this hidden tile][hi, lo]
+#pragma unroll
+                for (int To = 0; To < 2; ++To)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        w2[To][s2][0] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2);
+                        w2[To][s2][1] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2 + 1);
+                    }
+                if (tI + 1 < G::NT1) req1(tI + 1, w1[(tI + 1) & 1]);
+                SWF_WF_FENCE();
+                const u32x4 (&w)[6] = w1[tI & 1];
                 f32x16 acc = zero16;
 #pragma unroll
-                for (int s = 0; s < 3; ++s) acc = mma3(WF(G::F_W1 + (tI * 3 + s) * 2), WF(G::F_W1 + (tI * 3 + s) * 2 + 1), xh[s], xl[s], acc);
+                for (int s = 0; s < 3; ++s) acc = mma3(w[2 * s], w[2 * s + 1], xh[s], xl[s], acc);
                 float e[16];
 #pragma unroll
                 for (int g = 0; g < 4; ++g) {
@@ -342,10 +359,8 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
                 for (int s2 = 0; s2 < 2; ++s2) {
                     u32x4 hh, hl;
                     split8(e + 8 * s2, hh, hl);
-                    SWF_WF_FENCE();
-                    const int u = 2 * tI + s2;
-                    res0 = mma3(WF(G::F_W2 + (0 * G::KU + u) * 2), WF(G::F_W2 + (0 * G::KU + u) * 2 + 1), hh, hl, res0);
-                    res1 = mma3(WF(G::F_W2 + (1 * G::KU + u) * 2), WF(G::F_W2 + (1 * G::KU + u) * 2 + 1), hh, hl, res1);
+                    res0 = mma3(w2[0][s2][0], w2[0][s2][1], hh, hl, res0);
+                    res1 = mma3(w2[1][s2][0], w2[1][s2][1], hh, hl, res1);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // one hidden tile at a time
             }

@@ -1,2 +1,2 @@
 cd $GRAFT_REPO_ROOT
-bash tools/pmc_block.sh 0 pmc_r02f_l0enc g1 g2 g3 g4
+bash tools/pmc_block.sh 1 pmc_r02k_l1enc g1 g2 g3 g4
