@@ -29,7 +29,7 @@ from torch import nn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 BYTES_PER_ELEM = 4          # the residual stream is stored fp32 (DESIGN.md "Data layout")
-TRAFFIC_FILE = "r01z_traffic.json"   # committed PMC summary of the level-0 block kernel (tools/pmc_traffic.sh)
+TRAFFIC_FILE = "r02e_traffic.json"   # committed PMC summary of the level-0 block kernel (tools/pmc_traffic.sh)
 
 
 def parse():
@@ -224,7 +224,7 @@ def main():
             "config": {"workload": f"B={args.batch}/GPU {args.size}x{args.size} IR/visible pairs, win={cfg.window_size[0]}, "
                                    f"{cfg.n_levels}-level Swin-UNet fusion forward ({baseline_config_label(args, cfg, world)})",
                        "global_batch": args.batch * world, "precision_mode": args.precision,
-                       "arithmetic": "linear layers split-bf16 (bf16x3) MFMA, QK^T bf16 MFMA, P.V fp16 MFMA, everything else fp32"
+                       "arithmetic": "linear layers split-bf16 (bf16x3) MFMA, QK^T and P.V fp16 MFMA (fp32 accumulate), everything else fp32"
                                      if args.precision == "fast" else "exact fp32 (f32-input MFMA)",
                        "residual_stream": "fp32", "hip_graph": runner.graph_active, "graph_equals_eager": graph_equals_eager,
                        "collective": "rccl all_gather of the fused output" if world > 1 else "none",

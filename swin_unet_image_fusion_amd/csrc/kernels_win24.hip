@@ -79,7 +79,7 @@ struct G24 {
     static constexpr int NFRAG = F_W2 + 2 * KU;
     static constexpr size_t p_vec = size_t(NFRAG) * 1024;        // fp32 [lane half 2][64]: ln1 g/b, ln2 g/b, b2 (12 each)
     static constexpr int V_LN1G = 0, V_LN1B = 12, V_LN2G = 24, V_LN2B = 36, V_B2 = 48;
-    static constexpr size_t p_bias = p_vec + 2 * 64 * 4;         // fp32 [query block 2][key tile 2][reg 16][lane 64]
+    static constexpr size_t p_bias = p_vec + 2 * 64 * 4;         // fp32 [query block 2][lane 64][key tile 2][reg 16]
     static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
     // LDS (bytes): K images [buf 2][stream 2][key tile 2][k-step 2] x 1 KB, V^T images [buf 2][stream 2][pv-step 4] x 1 KB, vectors
     static constexpr size_t l_k = 0, l_v = l_k + 16 * 1024, l_vec = l_v + 16 * 1024, l_total = l_vec + 2 * 2 * 64 * 4;
@@ -311,14 +311,18 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
     const float* vec = lvec + (ws * 2 + hf) * 64;
     // relative-position bias of (stream, query block), both key tiles: C operand of the S^T MFMAs for the whole launch
     f32x16 bias[2];
-    // resident bias tile of this wave's token half; wave-uniform base (qb) in the scalar offset, lane in the vector offset
-    const int boff = __builtin_amdgcn_readfirstlane((int)G::p_bias + qb * 2 * 16 * 64 * 4);
+    // resident bias tile of this wave's token half: 128 contiguous bytes per lane, so every offset beyond the lane's own is an
+    // instruction immediate (no scalar registers held across the window loop for the reload after an edge window)
     auto load_bias = [&]() {
+        const int vo = lane * 128 + qb * (2 * 16 * 64 * 4);
 #pragma unroll
         for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
-            for (int i = 0; i < 16; ++i)
-                bias[kt][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(wrs, lane * 4, boff + (kt * 16 + i) * 256, 0));
+            for (int q4 = 0; q4 < 4; ++q4) {
+                const f32x4 t = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, vo + (kt * 16 + q4 * 4) * 4, (int)G::p_bias, 0));
+#pragma unroll
+                for (int e = 0; e < 4; ++e) bias[kt][q4 * 4 + e] = t[e];
+            }
     };
     load_bias();
     const bool half1 = hf != 0;
@@ -332,12 +336,16 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
         const int wy = wrem / nwx, wx = wrem - wy * nwx;
         const int buf = it & 1;
         // ---- the lane's token: window row 4qb + (r >> 3), column r & 7; cyclic shift = index arithmetic (a001:442-445) ----
-        const int ty = 4 * qb + (r >> 3), tx = r & 7;
-        int oy = wy * WS + ty + sh, ox = wx * WS + tx + sh;
-        oy = oy >= H ? oy - H : oy;
-        ox = ox >= W ? ox - W : ox;
+        // (derived from an opaque copy of the lane id inside the loop: kept across the loop these few values were what hipcc
+        // chose to spill; the wrap-around as an unsigned min needs no H / W splat registers)
+        int lane_w = lane;
+        asm volatile("" : "+v"(lane_w));
+        const int ty = 4 * qb + ((lane_w >> 3) & 3), tx = lane_w & 7;
+        unsigned oy = wy * WS + ty + sh, ox = wx * WS + tx + sh;
+        oy = oy < oy - (unsigned)H ? oy : oy - (unsigned)H;
+        ox = ox < ox - (unsigned)W ? ox : ox - (unsigned)W;
         // byte offset of the lane's first float4; padding tokens of a 7x7 window point beyond the buffer (reads 0, stores dropped)
-        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 24 + 4 * hf) * 4) : 0x80000000u;
+        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + (int)oy) * W + (int)ox) * 24 + 4 * (lane_w >> 5)) * 4) : 0x80000000u;
         // rows 24..31 of every output tile have zero weights: registers 12..15 stay zero
         auto load_rows = [&](f32x16& dstv) {
 #pragma unroll
@@ -576,10 +584,10 @@ __global__ __launch_bounds__(256) void pack24_kernel(Pack24Args a) {
         else if (which == 4) v = p.fc2.bias ? p.fc2.bias[c] : 0.f;
         vec[i] = v;
     }
-    // relative-position bias (a001:113-144), exp2 units, in S^T accumulator order: [query block][key tile][register][lane]
+    // relative-position bias (a001:113-144), exp2 units, the S^T accumulator registers of each lane: [query block][lane][key tile][register]
     float* bm = reinterpret_cast<float*>(dst + G::p_bias);
     for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
-        const int lane = i & 63, reg = (i >> 6) & 15, kt = (i >> 10) & 1, qb = i >> 11;
+        const int reg = i & 15, kt = (i >> 4) & 1, lane = (i >> 5) & 63, qb = i >> 11;
         const int key = 32 * kt + rho(reg, lane >> 5), q = 32 * qb + (lane & 31);
         const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7, ws = a.ws, tw = 2 * ws - 1;
         float v = 0.f;
