@@ -14,13 +14,17 @@ struct MlpFusedDesc {
     float* scratch; int64_t scratch_floats;         // nstream * mlp_fused_splits * M * C floats when splits > 1
     int M, C, HID;
     // optional (all or none): LayerNorm of the finished rows with these parameters — the next block's LN1 — written as split
-    // planes [M][C] by the reduce kernel.  Only honoured when mlp_fused_splits(C, HID) > 1 (mlp_fused_writes_ln).
+    // planes [M][C] by the reduce kernel (hidden splits > 1) or by the fused kernel's own epilogue (unsplit).
     const float* ln_gamma[2]; const float* ln_beta[2]; bf16_raw* ln_hi[2]; bf16_raw* ln_lo[2];
+    // optional (all or none): the attention half's tail folded into the prologue.  The rows that enter LN2 (and the residual add) are
+    // x + pbias + part0 + part1, summed in that order: the output projection's bias and its two head-group partial sums as
+    // written by launch_qkvattn (QkvAttnArgs::part).  x1: [M][C] scratch that receives those rows; must not alias x or out.
+    const float* part0[2]; const float* part1[2]; const float* pbias[2]; float* x1[2];
 };
 
 bool mlp_fused_supported(int C, int HID);
 int mlp_fused_splits(int C, int HID);
-inline bool mlp_fused_writes_ln(int C, int HID) { return mlp_fused_splits(C, HID) > 1; }
+inline bool mlp_fused_writes_ln(int, int) { return true; }
 int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream);
 
 }  // namespace swf

@@ -50,6 +50,9 @@ struct MlpArgs {
     int M, HID, splits, nchunks;
     // optional: LayerNorm of the finished rows (the NEXT block's LN1) as split planes, written by the reduce kernel
     const float* ln_gamma[2]; const float* ln_beta[2]; bf16* ln_hi[2]; bf16* ln_lo[2];
+    // optional: the attention half's tail.  The rows entering LN2 are x + pbias + part0 + part1 (the output projection's bias and its
+    // two head-group partial sums, qkv_attn_kernel); they are written to x1 (by the split-0 workgroups) and serve as the residual
+    const float* part0[2]; const float* part1[2]; const float* pbias[2]; float* x1[2];
 };
 
 __device__ __forceinline__ void mma3(f32x16& acc, const bf16x8 wh, const bf16x8 wl, const bf16x8 bh, const bf16x8 bl) {
@@ -123,6 +126,24 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         float4 v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + 16 * i + 4 * sub);
+        if (a.part0[s]) {   // attention residual: x + proj bias + the two head-group partials of the projection, fixed order
+            const float* p0 = a.part0[s] + (int64_t)m * C;
+            const float* p1 = a.part1[s] + (int64_t)m * C;
+            float4 u0[NV], u1[NV];
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                u0[i] = *reinterpret_cast<const float4*>(p0 + 16 * i + 4 * sub);
+                u1[i] = *reinterpret_cast<const float4*>(p1 + 16 * i + 4 * sub);
+            }
+            const bool wr = split == 0 && tile * 64 + row < a.M;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float4 pb = *reinterpret_cast<const float4*>(a.pbias[s] + 16 * i + 4 * sub);
+                v[i].x = ((v[i].x + pb.x) + u0[i].x) + u1[i].x; v[i].y = ((v[i].y + pb.y) + u0[i].y) + u1[i].y;
+                v[i].z = ((v[i].z + pb.z) + u0[i].z) + u1[i].z; v[i].w = ((v[i].w + pb.w) + u0[i].w) + u1[i].w;
+                if (wr) *reinterpret_cast<float4*>(a.x1[s] + (int64_t)m * C + 16 * i + 4 * sub) = v[i];
+            }
+        }
         float* gb = reinterpret_cast<float*>(h_hi);   // [2][C] fp32: gamma, beta
         float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < C / 2) gbv = *reinterpret_cast<const float4*>((tid < C / 4 ? a.gamma[s] : a.beta[s] - C) + 4 * tid);
@@ -297,19 +318,65 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
     __syncthreads();
     float* part = a.splits > 1 ? a.scratch + ((int64_t)(s * a.splits + split) * a.M) * C : nullptr;
     constexpr int C4 = C / 4;
+    if (part) {
 #pragma unroll 4
-    for (int idx = tid; idx < 64 * C4; idx += 256) {
-        const int row = idx / C4, c = (idx % C4) * 4;
+        for (int idx = tid; idx < 64 * C4; idx += 256) {
+            const int row = idx / C4, c = (idx % C4) * 4;
+            const int m = tile * 64 + row;
+            if (m >= a.M) continue;
+            *reinterpret_cast<float4*>(part + (int64_t)m * C + c) = *reinterpret_cast<const float4*>(otile + row * ORS + c);
+        }
+    } else {
+        // unsplit: the rows are final here.  4 threads per token row (64-byte segments), so the NEXT block's LN1 (optional) is a
+        // two-shuffle reduction over the finished row and leaves as split planes from the same registers: no LayerNorm launch
+        const int row = tid >> 2, sub = tid & 3;
         const int m = tile * 64 + row;
-        if (m >= a.M) continue;
-        float4 v = *reinterpret_cast<const float4*>(otile + row * ORS + c);
-        if (part) {
-            *reinterpret_cast<float4*>(part + (int64_t)m * C + c) = v;
-        } else {
-            const float4 b = *reinterpret_cast<const float4*>(a.b2[s] + c);
-            const float4 x = *reinterpret_cast<const float4*>(a.x[s] + (int64_t)m * C + c);
-            v.x += b.x + x.x; v.y += b.y + x.y; v.z += b.z + x.z; v.w += b.w + x.w;
-            *reinterpret_cast<float4*>(a.out[s] + (int64_t)m * C + c) = v;
+        const bool live = m < a.M;
+        constexpr int NV = C / 16;
+        float4 v[NV];
+        float sum = 0.f;
+#pragma unroll
+        for (int i = 0; i < NV; ++i) {
+            const int c = 16 * i + 4 * sub;
+            v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (live) {
+                float4 t = *reinterpret_cast<const float4*>(otile + row * ORS + c);
+                const float4 b = *reinterpret_cast<const float4*>(a.b2[s] + c);
+                // (with the attention tail fused, x1 holds this very thread's prologue stores: same row / column mapping)
+                const float4 x = *reinterpret_cast<const float4*>((a.part0[s] ? a.x1[s] : a.x[s]) + (int64_t)m * C + c);
+                t.x += b.x + x.x; t.y += b.y + x.y; t.z += b.z + x.z; t.w += b.w + x.w;
+                *reinterpret_cast<float4*>(a.out[s] + (int64_t)m * C + c) = t;
+                v[i] = t;
+            }
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+        if (a.ln_hi[s]) {
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            const float mean = sum * (1.0f / C);
+            float q = 0.f;
+#pragma unroll
+            for (int i = 0; i < NV; ++i) {
+                const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            q += __shfl_xor(q, 1);
+            q += __shfl_xor(q, 2);
+            const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+            if (live) {
+#pragma unroll
+                for (int i = 0; i < NV; ++i) {
+                    const int c = 16 * i + 4 * sub;
+                    const float4 g = *reinterpret_cast<const float4*>(a.ln_gamma[s] + c), b = *reinterpret_cast<const float4*>(a.ln_beta[s] + c);
+                    const float n[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
+                                        (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
+                    bf16x4 hi, lo;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) { hi[j] = (bf16)n[j]; lo[j] = (bf16)(n[j] - (float)hi[j]); }
+                    *reinterpret_cast<bf16x4*>(a.ln_hi[s] + (int64_t)m * C + c) = hi;
+                    *reinterpret_cast<bf16x4*>(a.ln_lo[s] + (int64_t)m * C + c) = lo;
+                }
+            }
         }
     }
     SWF_PROBE(41);
@@ -421,15 +488,18 @@ int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
     dim3 grid((a.M + 63) / 64, a.splits, nstream);
     hipLaunchKernelGGL((mlp_fused_kernel<C>), grid, dim3(256), lds, stream, a);
     SWF_TRY(check_launch("mlp_fused"));
+    MlpArgs ra = a;   // the reduce kernels' residual is the row that entered LN2
+    for (int s = 0; s < nstream; ++s)
+        if (a.part0[s]) ra.x[s] = a.x1[s];
     if (a.splits > 1 && a.ln_hi[0]) {
         constexpr int chunks = C / 4, L = chunks > 32 ? 64 : 32, NCH = (chunks + L - 1) / L;   // as launch_layernorm picks them
         dim3 rgrid((unsigned)cdiv64((int64_t)a.M * L, 256), nstream);
-        hipLaunchKernelGGL((mlp_reduce_ln_kernel<NCH>), rgrid, dim3(256), 0, stream, a, C, L);
+        hipLaunchKernelGGL((mlp_reduce_ln_kernel<NCH>), rgrid, dim3(256), 0, stream, ra, C, L);
         return check_launch("mlp_reduce_ln");
     }
     if (a.splits > 1) {
         dim3 rgrid((unsigned)std::min<int64_t>(cdiv64((int64_t)a.M * C, 1024), 2048), nstream);
-        hipLaunchKernelGGL(mlp_reduce_kernel, rgrid, dim3(256), 0, stream, a, C);
+        hipLaunchKernelGGL(mlp_reduce_kernel, rgrid, dim3(256), 0, stream, ra, C);
         return check_launch("mlp_reduce");
     }
     return SWF_OK;
@@ -462,11 +532,18 @@ int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream) {
         a.w2_hi[s] = reinterpret_cast<const bf16*>(d.w2_hi[s]); a.w2_lo[s] = reinterpret_cast<const bf16*>(d.w2_lo[s]);
         a.b1[s] = d.b1[s]; a.b2[s] = d.b2[s];
     }
+    if (d.part0[0]) {
+        for (int s = 0; s < nstream; ++s) {
+            if (!d.part0[s] || !d.part1[s] || !d.pbias[s] || !d.x1[s]) return fail(SWF_ERR_NULL, "mlp_fused: attention-tail inputs must be given for every stream");
+            if (d.x1[s] == d.x[s] || d.x1[s] == d.out[s]) return fail(SWF_ERR_UNSUPPORTED, "mlp_fused: x1 must not alias x / out");
+            a.part0[s] = d.part0[s]; a.part1[s] = d.part1[s]; a.pbias[s] = d.pbias[s]; a.x1[s] = d.x1[s];
+        }
+    }
     a.M = d.M; a.HID = d.HID;
     a.splits = mlp_fused_splits(d.C, d.HID);
     a.nchunks = d.HID / 128 / a.splits;
     a.scratch = d.scratch;
-    if (d.ln_hi[0] && a.splits > 1)
+    if (d.ln_hi[0])
         for (int s = 0; s < nstream; ++s) {
             a.ln_gamma[s] = d.ln_gamma[s]; a.ln_beta[s] = d.ln_beta[s];
             a.ln_hi[s] = reinterpret_cast<bf16*>(d.ln_hi[s]); a.ln_lo[s] = reinterpret_cast<bf16*>(d.ln_lo[s]);

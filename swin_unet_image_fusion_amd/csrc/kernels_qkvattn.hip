@@ -44,7 +44,9 @@ struct QA {
     static constexpr int NFRAG = HEADS * 3 * KS * 2;                    // [head][q,k,v][k-step][hi,lo] x 1 KB
     static constexpr size_t p_bvec = size_t(NFRAG) * 1024;              // fp32 [head][q,k,v][32]: bias in virtual-channel order
     static constexpr size_t p_bias = p_bvec + size_t(HEADS) * 3 * 32 * 4;   // fp32 [query tile 2][key tile 2][reg 16][lane 64]
-    static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
+    static constexpr size_t p_proj = p_bias + size_t(2) * 2 * 16 * 64 * 4;   // output projection as B fragments: [head group][32-channel tile][head in group][k-step 2][hi,lo] x 1 KB
+    static constexpr int NT = C / 32, NPF = (HEADS / HG) * NT * HG * 2 * 2;
+    static constexpr size_t p_total = p_proj + size_t(NPF) * 1024;
     static constexpr int XS = C * 2 + 16;                               // LDS row stride (bytes) of a staged plane
     static constexpr size_t l_plane = size_t(64) * XS, l_tile = 2 * l_plane;
     static constexpr size_t l_xq = 0, l_xkv = l_tile, l_k = 2 * l_tile, l_v = l_k + HG * 4 * 1024, l_total = l_v + HG * 4 * 1024;
@@ -56,6 +58,7 @@ struct QaDev {
     const char* packed[2];
     const bf16* xn_hi[2]; const bf16* xn_lo[2];
     bf16* o_hi[2]; bf16* o_lo[2];
+    float* part[2][2];   // [head group][stream]: projection partial sums [token][C] fp32 (nullptr: write O planes instead)
     int B, H, W, shift, cross, nstream;
 };
 
@@ -80,6 +83,18 @@ __device__ __forceinline__ u32x4 pack8_f16(const float* v) {
         o[p] = __builtin_bit_cast(unsigned, h);
     }
     return o;
+}
+// 8 fp32 values -> one k-step fragment in split-bf16 (hi = bf16(v), lo = bf16(v - hi))
+__device__ __forceinline__ void split8(const float* v, u32x4& hi, u32x4& lo) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const bf16x2 h = {(bf16)v[2 * p], (bf16)v[2 * p + 1]};
+        const unsigned hu = __builtin_bit_cast(unsigned, h);
+        const float h0 = __builtin_bit_cast(float, hu << 16), h1 = __builtin_bit_cast(float, hu & 0xffff0000u);
+        const bf16x2 l = {(bf16)(v[2 * p] - h0), (bf16)(v[2 * p + 1] - h1)};
+        hi[p] = hu;
+        lo[p] = __builtin_bit_cast(unsigned, l);
+    }
 }
 // a = the value of lanes 0..31 (in both halves), b = the value of lanes 32..63 (kernels_win24.hip)
 __device__ __forceinline__ void halves(float v, float& a, float& b) {
@@ -292,11 +307,11 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
         t = mfma_f16(vsrc[ps * 64], pack8_f16(p), ps == 0 ? zero16 : t);
     }
     QA_STAMP(4);
-    // ---- normalise (row 24 = register 12 of lane half 0 holds the denominator) and write O as split-bf16 planes ----
-    {
-        float den, unused;
-        halves(t[12], den, unused);
-        const float inv = __builtin_amdgcn_rcpf(den);
+    // ---- normalise (row 24 = register 12 of lane half 0 holds the denominator) ----
+    float den, unused;
+    halves(t[12], den, unused);
+    const float inv = __builtin_amdgcn_rcpf(den);
+    if (a.part[0][st] == nullptr) {   // O leaves as split-bf16 planes (the projection GEMM's input)
         const int64_t orow = (int64_t)tok_index(32 * qt + r) * (G::HEADS * G::D) + head * G::D + 4 * hf;
         bf16* oh = a.o_hi[st] + orow;
         bf16* ol = a.o_lo[st] + orow;
@@ -311,6 +326,54 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
             }
             *reinterpret_cast<bf16x4*>(oh + 8 * g) = h4;
             *reinterpret_cast<bf16x4*>(ol + 8 * g) = l4;
+        }
+    } else {
+        // ---- output projection of this head group (a001:470-472), partial over the group's 4 x 24 channels:
+        //      P[token][c] = sum_{head, d} O[token][head][d] . Wp[c][head*24 + d].  The O^T accumulator registers of a lane,
+        //      split to bf16 hi / lo, ARE the A fragments (rows = tokens, k = the head's virtual channels in accumulator order;
+        //      the pack stores Wp's k in that order, zero for the padding channels 24..31 — channel 24 holds the denominator).
+        //      The 8 waves exchange them through LDS (the dead token tile) and share the C / 32 output tiles: wave (hl, tt)
+        //      owns tiles hl, hl + 4, ... of token half tt.  The other head group's partial is added by the consumer (the fused
+        //      MLP kernel's prologue), in fixed order.
+        constexpr int NT = G::NT;
+        const int pbase = (int)(G::p_proj / 1024) + hg * NT * G::HG * 4;
+        auto PFRAG = [&](int tile, int f) {   // f = (head in group * 2 + k-step) * 2 + hi/lo
+            return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (pbase + tile * G::HG * 4 + f) * 1024, 0));
+        };
+        u32x4 wp[G::HG * 4];
+#pragma unroll
+        for (int f = 0; f < G::HG * 4; ++f) wp[f] = PFRAG(hl, f);   // in flight during the exchange
+        float ov[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) ov[i] = t[i] * inv;
+        u32x4* ofr = reinterpret_cast<u32x4*>(smem + G::l_xq);   // [head in group][token half][k-step][hi,lo][lane]
+        {
+            u32x4 h0, l0, h1, l1;
+            split8(ov, h0, l0);
+            split8(ov + 8, h1, l1);
+            u32x4* dst = ofr + ((hl * 2 + tt) * 4) * 64 + lane;
+            dst[0] = h0; dst[64] = l0; dst[128] = h1; dst[192] = l1;
+        }
+        __syncthreads();
+        int tokrow[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) tokrow[i] = tok_index(32 * tt + rho(i, hf)) * C;
+        float* pout = a.part[hg][st];
+        for (int tile = hl; tile < NT; tile += G::HG) {
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int h2 = 0; h2 < G::HG; ++h2)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const u32x4* src = ofr + ((h2 * 2 + tt) * 4 + 2 * ks) * 64 + lane;
+                    acc = mma3(src[0], src[64], wp[(h2 * 2 + ks) * 2], wp[(h2 * 2 + ks) * 2 + 1], acc);
+                }
+            if (tile + G::HG < NT) {
+#pragma unroll
+                for (int f = 0; f < G::HG * 4; ++f) wp[f] = PFRAG(tile + G::HG, f);
+            }
+#pragma unroll
+            for (int i = 0; i < 16; ++i) pout[tokrow[i] + 32 * tile + r] = acc[i];
         }
     }
     QA_STAMP(5);
@@ -335,6 +398,18 @@ __global__ __launch_bounds__(256) void qa_pack_kernel(QaPackArgs a) {
         }
         const bf16 hi = (bf16)val;
         reinterpret_cast<bf16*>(a.dst)[idx] = hl ? (bf16)(val - (float)hi) : hi;
+    }
+    // output projection, B fragments: lane (r, hf) element e of (group, tile, head in group, k-step) = Wp[32 tile + r][head*24 + vc],
+    // vc = the row of accumulator register 8 ks + e in lane half hf
+    bf16* pf = reinterpret_cast<bf16*>(a.dst + G::p_proj);
+    for (int idx = gtid; idx < G::NPF * 512; idx += gsz) {
+        const int f = idx >> 9, lane = (idx >> 3) & 63, e = idx & 7, r = lane & 31, hf = lane >> 5;
+        const int hl = f & 1, ks = (f >> 1) & 1, h2 = (f >> 2) % G::HG, tile = (f / (4 * G::HG)) % G::NT, hg = f / (4 * G::HG * G::NT);
+        const int vc = rho(8 * ks + e, hf);
+        float val = 0.f;
+        if (vc < G::D) val = a.p.proj.weight[(int64_t)(32 * tile + r) * (G::HEADS * G::D) + (hg * G::HG + h2) * G::D + vc];
+        const bf16 hi = (bf16)val;
+        pf[idx] = hl ? (bf16)(val - (float)hi) : hi;
     }
     float* bvec = reinterpret_cast<float*>(a.dst + G::p_bvec);
     for (int i = gtid; i < G::HEADS * 3 * 32; i += gsz) {
@@ -381,7 +456,10 @@ int launch_qkvattn(const swf_block_desc& d, const QkvAttnArgs& a, int nstream, h
         dv.packed[s] = static_cast<const char*>(a.packed[s]);
         dv.xn_hi[s] = reinterpret_cast<const bf16*>(a.xn_hi[s]); dv.xn_lo[s] = reinterpret_cast<const bf16*>(a.xn_lo[s]);
         dv.o_hi[s] = reinterpret_cast<bf16*>(a.o_hi[s]); dv.o_lo[s] = reinterpret_cast<bf16*>(a.o_lo[s]);
+        dv.part[0][s] = a.part[0][s]; dv.part[1][s] = a.part[1][s];
     }
+    if ((dv.part[0][0] != nullptr) != (dv.part[1][0] != nullptr) || (nstream == 2 && (dv.part[0][1] != nullptr) != (dv.part[0][0] != nullptr)))
+        return fail(SWF_ERR_NULL, "qkvattn: projection partial buffers must be given for both head groups and streams or not at all");
     dv.B = a.B; dv.H = a.H; dv.W = a.W; dv.shift = a.shift; dv.cross = a.cross; dv.nstream = nstream;
     const int nwin = a.B * (a.H / 8) * (a.W / 8);
     hipLaunchKernelGGL((qkv_attn_kernel<192>), dim3(nwin, nstream, 2), dim3(512), G::l_total, stream, dv);

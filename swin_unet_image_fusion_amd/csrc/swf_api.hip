@@ -226,6 +226,9 @@ static size_t deep_block_ws(const swf_block_desc* d, int nstream, int B, int H, 
     int64_t sk = std::max((int64_t)gemm_sp_splitk_for((int)HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for((int)hid, SP_EPI_F32));
     if (mlp_fused_supported((int)C, (int)hid)) sk = std::max(sk, (int64_t)mlp_fused_splits((int)C, (int)hid));
     t += carve_bytes({sk > 1 ? sk * nstream * N * C : 0});
+    // projection folded into the attention / MLP launches (deep_block_impl): two head-group partials + the attention-residual rows
+    if (qkvattn_supported(*d) && mlp_fused_supported((int)C, (int)hid) && HD == C)
+        for (int s = 0; s < nstream; ++s) t += carve_bytes({N * C, N * C, N * C});
     return t;
 }
 
@@ -263,6 +266,16 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
     if (fused_mlp) skn = std::max(skn, (int64_t)mlp_fused_splits(C, hid));
     const int64_t sk_floats = skn > 1 ? skn * nstream * N * C : 0;
     float* sk = ws.floats(sk_floats);
+    // Output projection folded into its neighbours (C = 192 levels): qkv_attn writes the two head-group partial sums of
+    // O . Wp^T, the fused MLP kernel's prologue adds x + bias + both and normalises — no projection GEMM launch, O never
+    // reaches HBM.  (Carved last so the LN1 planes keep their offsets from block to block.)
+    static const bool no_qkvattn = std::getenv("SWF_NO_QKVATTN") != nullptr;     // A/B switches
+    static const bool no_projfuse = std::getenv("SWF_NO_PROJFUSE") != nullptr;
+    const bool fused_attn_shape = !no_qkvattn && qkvattn_supported(*desc) && N <= INT32_MAX / 256;
+    const bool proj_fused = fused_attn_shape && fused_mlp && !no_projfuse && HD == C;
+    float *part[2][2] = {{nullptr, nullptr}, {nullptr, nullptr}}, *x1[2] = {nullptr, nullptr};
+    if (qkvattn_supported(*desc) && mlp_fused_supported(C, hid) && HD == C)
+        for (int s = 0; s < nstream; ++s) { part[0][s] = ws.floats(N * C); part[1][s] = ws.floats(N * C); x1[s] = ws.floats(N * C); }
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "deep block workspace too small (need %zu B)", ws.used);
     DeepWeights wv[2];
     for (int s = 0; s < nstream; ++s) {
@@ -275,12 +288,13 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         for (int s = 0; s < nstream; ++s) l1.p[s] = LnProb{xin[s], nullptr, pp[s]->ln1.gamma, pp[s]->ln1.beta, xn_hi[s], xn_lo[s]};
         SWF_TRY(launch_layernorm(l1, nstream, N, C, 0, stream));
     }
-    static const bool no_qkvattn = std::getenv("SWF_NO_QKVATTN") != nullptr;   // A/B switch
-    const bool fused_attn = !no_qkvattn && qkvattn_supported(*desc) && wv[0].qa && (nstream == 1 || wv[1].qa) && N <= INT32_MAX / 256;
-    if (fused_attn) {   // Q/K/V projections + window attention in one launch
+    const bool fused_attn = fused_attn_shape && wv[0].qa && (nstream == 1 || wv[1].qa);
+    const bool fold_proj = proj_fused && fused_attn && pp[0]->attn.proj.bias && (nstream == 1 || pp[1]->attn.proj.bias);
+    if (fused_attn) {   // Q/K/V projections + window attention (+ output projection partials) in one launch
         QkvAttnArgs qa{};
         for (int s = 0; s < nstream; ++s) {
             qa.packed[s] = wv[s].qa; qa.xn_hi[s] = xn_hi[s]; qa.xn_lo[s] = xn_lo[s]; qa.o_hi[s] = o_hi[s]; qa.o_lo[s] = o_lo[s];
+            if (fold_proj) { qa.part[0][s] = part[0][s]; qa.part[1][s] = part[1][s]; }
         }
         qa.B = B; qa.H = H; qa.W = W; qa.shift = desc->attn.shift; qa.cross = cross;
         SWF_TRY(launch_qkvattn(*desc, qa, nstream, stream));
@@ -310,12 +324,13 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
     gp.scratch = sk; gp.scratch_floats = sk_floats;
     for (int s = 0; s < nstream; ++s)
         gp.p[s] = SpGemmProb{o_hi[s], o_lo[s], wv[s].p_hi, wv[s].p_lo, pp[s]->attn.proj.bias, xin[s], xout[s], nullptr, nullptr};
-    SWF_TRY(launch_gemm_sp(gp, nstream, (int)N, C, HD, C, SP_EPI_F32, stream));
+    if (!fold_proj) SWF_TRY(launch_gemm_sp(gp, nstream, (int)N, C, HD, C, SP_EPI_F32, stream));
     // MLP half (a004:29-38 around a003:46-50)
     if (fused_mlp) {   // LN2 + fc1 + ELU + fc2 + residual in one launch (+ a fixed-order reduce over the hidden splits)
         MlpFusedDesc md{};
         for (int s = 0; s < nstream; ++s) {
-            md.x[s] = xout[s]; md.out[s] = xout[s]; md.gamma[s] = pp[s]->ln2.gamma; md.beta[s] = pp[s]->ln2.beta;
+            md.x[s] = fold_proj ? xin[s] : xout[s]; md.out[s] = xout[s]; md.gamma[s] = pp[s]->ln2.gamma; md.beta[s] = pp[s]->ln2.beta;
+            if (fold_proj) { md.part0[s] = part[0][s]; md.part1[s] = part[1][s]; md.pbias[s] = pp[s]->attn.proj.bias; md.x1[s] = x1[s]; }
             md.w1_hi[s] = wv[s].w1f_hi; md.w1_lo[s] = wv[s].w1f_lo; md.w2_hi[s] = wv[s].w2f_hi; md.w2_lo[s] = wv[s].w2f_lo;
             md.b1[s] = pp[s]->fc1.bias; md.b2[s] = pp[s]->fc2.bias;
         }
