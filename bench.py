@@ -196,8 +196,15 @@ def main():
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
+    # every step = forward of the local shard + all-gather of the fused outputs; the gather of step i runs on RCCL's stream under
+    # the forward of step i+1 and is waited for (stream-level) one step later; all K gathers have completed at the final sync
+    pending = None
     for _ in range(args.steps):
-        fused = runner.step(ir, vis)
+        handle = runner.step_async(ir, vis)
+        if pending is not None:
+            fused = pending.wait()
+        pending = handle
+    fused = pending.wait()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -227,7 +234,7 @@ def main():
                        "arithmetic": "linear layers split-bf16 (bf16x3) MFMA, QK^T and P.V fp16 MFMA (fp32 accumulate), everything else fp32"
                                      if args.precision == "fast" else "exact fp32 (f32-input MFMA)",
                        "residual_stream": "fp32", "hip_graph": runner.graph_active, "graph_equals_eager": graph_equals_eager,
-                       "collective": "rccl all_gather of the fused output" if world > 1 else "none",
+                       "collective": "rccl all_gather_into_tensor of the fused output per step, overlapped with the next step's forward" if world > 1 else "none",
                        "weights": "random-init (numpy PCG64 recipe, seed 0)"},
         }
         line["roofline"] = level0_block_roofline(model, args.batch, args.size, args.precision)

@@ -26,8 +26,27 @@ def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int, int]
     return start, stop, per
 
 
+class GatherHandle:
+    """Result of ShardedFusion.step_async(): wait() returns the gathered tensor once the collective is ordered before the
+    caller's stream (GPU: a stream-level wait, the host does not block; gloo: a host wait)."""
+
+    def __init__(self, tensor: torch.Tensor, work=None):
+        self._tensor, self._work = tensor, work
+
+    def wait(self) -> torch.Tensor:
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        return self._tensor
+
+
 class ShardedFusion:
     """step(ir, vis): run this rank's pairs and return the fused output of ALL ranks, rank-major.
+
+    step_async(ir, vis) returns a GatherHandle instead: the all-gather runs on the process group's own stream (RCCL over
+    xGMI) while the caller enqueues the NEXT step's forward, and only handle.wait() orders it before the caller's stream.
+    The local output is first copied into one of two staging buffers (the captured graph rewrites its output buffer at
+    the next replay) and gathered into one of two result buffers, so a handle stays valid until the second step after it.
 
     forward_fn defaults to `model(ir, vis)` (the HIP path).  With `use_graph` the forward is captured
     into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed: ~100 kernel launches per forward
@@ -42,15 +61,20 @@ class ShardedFusion:
     output buffer: it is overwritten by the next step — clone it to keep it."""
 
     def __init__(self, model=None, world_size: int = 1, rank: int = 0, use_graph: bool = False,
-                 forward_fn: Optional[Callable] = None, group=None):
+                 forward_fn: Optional[Callable] = None, group=None, force_collective: bool = False):
+        # force_collective: issue the all-gather even at world_size 1 (a one-rank RCCL group exercises the GPU branch on a
+        # single-GPU box: tests/test_gpu_parity.py)
         self.model, self.world_size, self.rank, self.group = model, world_size, rank, group
+        self.force_collective = force_collective
         self.forward_fn = forward_fn or (lambda a, b: model(a, b))
         self.use_graph = use_graph
         self.graph_active = False
         self._graph = None
         self._static = None   # (ir, vis, out) of the captured graph
         self._key = None      # (input shape, model.graph_key()) the graph was captured for
-        self._gathered = None
+        self._gathered = [None, None]   # double-buffered: step i+1 may run while step i's result is still being gathered / read
+        self._stage = [None, None]
+        self._slot = 0
         self._cap_stream = None   # one capture stream for the runner's lifetime: the library workspace is keyed by stream
         self.captures = 0
 
@@ -90,21 +114,30 @@ class ShardedFusion:
         return s_out
 
     # -- collective ------------------------------------------------------------------------------
-    def gather(self, local_out: torch.Tensor) -> torch.Tensor:
-        if self.world_size == 1:
-            return local_out
+    def gather_async(self, local_out: torch.Tensor) -> GatherHandle:
+        if self.world_size == 1 and not self.force_collective:
+            return GatherHandle(local_out)
+        self._slot ^= 1
+        k = self._slot
         shape = (self.world_size * local_out.shape[0],) + tuple(local_out.shape[1:])
-        if self._gathered is None or self._gathered.shape != shape or self._gathered.device != local_out.device:
-            self._gathered = torch.empty(shape, dtype=local_out.dtype, device=local_out.device)
-        local_out = local_out.contiguous()
+        if self._gathered[k] is None or self._gathered[k].shape != shape or self._gathered[k].device != local_out.device:
+            self._gathered[k] = torch.empty(shape, dtype=local_out.dtype, device=local_out.device)
+            self._stage[k] = torch.empty(tuple(local_out.shape), dtype=local_out.dtype, device=local_out.device)
+        self._stage[k].copy_(local_out)   # the collective reads a buffer nothing rewrites while it is in flight
         if local_out.is_cuda:
-            dist.all_gather_into_tensor(self._gathered, local_out, group=self.group)
+            work = dist.all_gather_into_tensor(self._gathered[k], self._stage[k], group=self.group, async_op=True)
         else:   # gloo
-            dist.all_gather(list(self._gathered.chunk(self.world_size, dim=0)), local_out, group=self.group)
-        return self._gathered
+            work = dist.all_gather(list(self._gathered[k].chunk(self.world_size, dim=0)), self._stage[k], group=self.group, async_op=True)
+        return GatherHandle(self._gathered[k], work)
+
+    def gather(self, local_out: torch.Tensor) -> torch.Tensor:
+        return self.gather_async(local_out).wait()
+
+    def step_async(self, ir_shard: torch.Tensor, vis_shard: torch.Tensor) -> GatherHandle:
+        return self.gather_async(self.local_forward(ir_shard, vis_shard))
 
     def step(self, ir_shard: torch.Tensor, vis_shard: torch.Tensor) -> torch.Tensor:
-        return self.gather(self.local_forward(ir_shard, vis_shard))
+        return self.step_async(ir_shard, vis_shard).wait()
 
     def fuse_global(self, ir: torch.Tensor, vis: torch.Tensor) -> torch.Tensor:
         """Every rank passes the same global batch; returns the full fused batch on every rank."""

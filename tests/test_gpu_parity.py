@@ -3,6 +3,8 @@ compared with (a) golden vectors captured from the real reference and (b) the CP
 seeded inputs.  Bars: exact-fp32 tier <= 2e-5 relative (summation-order noise only); 'fast' precision
 <= 1e-3 relative (the north-star tolerance; SURVEY.md §7 hard part 3), metric = rel-L2 and max|err|/max|ref|.
 """
+import os
+
 import pytest
 import torch
 from torch import nn
@@ -372,6 +374,39 @@ def test_sharded_fusion_graph_replay_follows_weights_and_inputs():
     o4 = runner.step(ir1, vis1).clone()
     assert runner.captures == 3 and torch.equal(o4, m(ir1, vis1)) and not torch.equal(o4, o3)
     assert torch.equal(runner.fuse_global(ir2, vis2), m(ir2, vis2))
+
+
+def test_pipelined_gather_on_a_one_rank_rccl_group():
+    """The GPU branch of the collective (all_gather_into_tensor, async, double-buffered) on the only topology a one-GPU box
+    offers: a one-rank RCCL group.  Steps are issued bench.py's way — the wait for step i comes after step i+1 was enqueued —
+    and each handle must hold its own step's output."""
+    import torch.distributed as dist
+    created = False
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        cfg = CONFIGS["win8_4stage"]
+        m = MyModel(**cfg.model_kwargs(_elu())).eval()
+        load_recipe_into(m, seed=0, flavor="default")
+        m.to(DEV)
+        runner = ShardedFusion(m, world_size=1, rank=0, use_graph=True, force_collective=True)
+        ir1, vis1 = (torch.from_numpy(a).to(DEV) for a in synthetic_pair(2, 128, 128, 1, 2))
+        ir2, vis2 = (torch.from_numpy(a).to(DEV) for a in synthetic_pair(2, 128, 128, 3, 4))
+        h1 = runner.step_async(ir1, vis1)
+        h2 = runner.step_async(ir2, vis2)
+        g1, g2 = h1.wait(), h2.wait()
+        h3 = runner.step_async(ir1, vis1)   # reuses g1's buffers only now
+        assert g1.data_ptr() != g2.data_ptr()
+        assert torch.equal(g2, m(ir2, vis2))
+        g3 = h3.wait()
+        assert g3.data_ptr() == g1.data_ptr() and torch.equal(g3, m(ir1, vis1))
+        assert torch.equal(runner.step(ir2, vis2), m(ir2, vis2))
+    finally:
+        if created:
+            dist.destroy_process_group()
 
 
 def test_load_state_dict_roundtrip_refreshes_arena():

@@ -49,6 +49,16 @@ def _worker(rank, world, port, batch, q):
         with torch.no_grad():
             g = runner.step(ir[a:b], vis[a:b])
         ok = ok and torch.allclose(g, ref[: g.shape[0]], rtol=0, atol=1e-6)
+        # pipelined steps (bench.py's loop): the gather of step i is waited for after step i+1 has been issued; results
+        # stay valid for two steps (double-buffered) and each equals its own step's unsharded rows
+        if b > a:
+            with torch.no_grad():
+                flipped = fwd(vis, ir)
+                h0 = runner.step_async(ir[a:b], vis[a:b])
+                h1 = runner.step_async(vis[a:b], ir[a:b])
+                g0, g1 = h0.wait(), h1.wait()
+            ok = ok and g0.data_ptr() != g1.data_ptr()
+            ok = ok and torch.allclose(g0, ref[: g0.shape[0]], rtol=0, atol=1e-6) and torch.allclose(g1, flipped[: g1.shape[0]], rtol=0, atol=1e-6)
         q.put((rank, bool(ok)))
     finally:
         dist.destroy_process_group()
