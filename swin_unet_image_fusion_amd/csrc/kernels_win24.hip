@@ -83,6 +83,12 @@ struct G24 {
     static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
     // LDS (bytes): K images [buf 2][stream 2][key tile 2][k-step 2] x 1 KB, V^T images [buf 2][stream 2][pv-step 4] x 1 KB, vectors
     static constexpr size_t l_k = 0, l_v = l_k + 16 * 1024, l_vec = l_v + 16 * 1024, l_total = l_vec + 2 * 2 * 64 * 4;
+    // 16x16 windows (window24w16_kernel): the bias section holds one S^T tile per key-tile / query-tile distance kt - qb + 7
+    // (a tile = two window rows of 16 tokens, so the relative positions of a tile pair depend on that distance only):
+    // fp32 [distance 15][lane 64][reg 16]
+    static constexpr size_t p_total16 = p_bias + size_t(15) * 64 * 16 * 4;
+    // LDS: K images [stream 2][key tile 8][k-step 2] x 1 KB, V^T images [stream 2][pv-step 16] x 1 KB (single-buffered), vectors
+    static constexpr size_t l_k16 = 0, l_v16 = 32 * 1024, l_vec16 = 64 * 1024, l_total16 = l_vec16 + 2 * 2 * 64 * 4;
 };
 
 struct Win24Args {
@@ -509,6 +515,278 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 16x16 windows (BASELINE config 5): the same register-resident pipeline per 32-token tile, attention over 256 keys.
+//
+// A window is 8 token tiles of 32 (tile j = window rows 2j, 2j+1).  Wave (stream w >> 1, half w & 1) owns tiles 4*half .. +3 of
+// its stream.  Phase A: LN1 + Q/K/V of its four tiles — the 12 weight fragments are fetched ONCE per window and serve all
+// four —, Q fragments stay in registers, K / V^T images of all 256 keys go to LDS (64 KB for both streams; two workgroups
+// per CU).  One barrier.  Phase B, per tile: attention with an online softmax over four chunks of 64 keys, then projection,
+// LN2, MLP and the store exactly as in window24_kernel.  A second barrier frees the images for the next window.
+//
+// Online softmax in this layout: a chunk is the 8x8 kernel's whole attention (S^T with the bias tile as C operand, row maximum,
+// S^T again with -max on the spare k slot, exp2, V^T.P^T with the constant-one channel), followed by o = o * 2^(m_old - m_new)
+// + t on the four accumulator rows of the head.  The shift that enters the second S^T pass is -max ROUNDED TO f16, so the
+// running maximum is kept as that rounded value: the rescale factor then matches what earlier chunks were shifted by.
+// Shift masks stay structural: the row seam (window row 8) separates key tiles 0..3 from 4..7 — a masked chunk is skipped —,
+// the column seam (column 8) is bit 2 of the accumulator register index against bit 3 of the lane's query column: -inf added
+// to those bias registers of the chunk's two tiles.
+template <int HID>
+__global__ __launch_bounds__(256, 2) void window24w16_kernel(Win24Args args) {
+    using G = G24<HID>;
+    extern __shared__ __attribute__((aligned(16))) char smem16[];
+    u32x4* kimg = reinterpret_cast<u32x4*>(smem16 + G::l_k16);   // [stream][key tile 8][k-step 2][lane]
+    u32x4* vimg = reinterpret_cast<u32x4*>(smem16 + G::l_v16);   // [stream][pv-step 16][lane]
+    float* lvec = reinterpret_cast<float*>(smem16 + G::l_vec16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ws = wave >> 1, pw = wave & 1, r = lane & 31, hf = lane >> 5;
+    const int H = args.H, W = args.W, nwx = W / 16, nwy = H / 16, npi = nwx * nwy;
+    const int nwin = args.B * npi;
+    const int sh = args.shift ? 8 : 0;
+    const int kvs = args.cross ? 1 - ws : ws;
+
+    for (int i = tid; i < 2 * 2 * 64; i += 256) lvec[i] = reinterpret_cast<const float*>(args.packed[i >> 7] + G::p_vec)[i & 127];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total16, 0x00020000);
+    const int act_bytes = args.B * H * W * 24 * 4;   // < 2^31 (launch_win24)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(args.in[ws])), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, act_bytes, 0x00020000);
+    const unsigned loff = (unsigned)lane * 16u;
+    auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };
+    auto WK = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, loff, f * 1024, 0)); };
+    const float* vec = lvec + (ws * 2 + hf) * 64;
+    const bool half1 = hf != 0;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        W24_FENCE();
+        const int b = win / npi, wrem = win - b * npi;
+        const int wy = wrem / nwx, wx = wrem - wy * nwx;
+        // byte offset of the lane's first float4 of its token in tile j: window row 2j + (r >> 4), column r & 15; the cyclic
+        // shift is index arithmetic (a001:442-445)
+        auto tokoff_of = [&](int j) {
+            int lane_w = lane;
+            asm volatile("" : "+v"(lane_w));
+            unsigned oy = wy * 16 + 2 * j + ((lane_w >> 4) & 1) + sh, ox = wx * 16 + (lane_w & 15) + sh;
+            oy = oy < oy - (unsigned)H ? oy : oy - (unsigned)H;
+            ox = ox < ox - (unsigned)W ? ox : ox - (unsigned)W;
+            return (unsigned)((((b * H + (int)oy) * W + (int)ox) * 24 + 4 * (lane_w >> 5)) * 4);
+        };
+        auto load_rows = [&](f32x16& dstv, unsigned tokoff) {
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, tokoff, 32 * a, 0));
+                dstv[4 * a] = v.x; dstv[4 * a + 1] = v.y; dstv[4 * a + 2] = v.z; dstv[4 * a + 3] = v.w;
+            }
+            dstv[12] = dstv[13] = dstv[14] = dstv[15] = 0.f;
+        };
+
+        // ---- phase A: LN1 + Q/K/V of the wave's four tiles; the weight fragments are fetched once ----
+        u32x4 qf[4][2];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { qf[q][0] = u32x4{0u, 0u, 0u, 0u}; qf[q][1] = u32x4{0u, 0u, 0u, 0u}; }
+        {
+            u32x4 wq[4], wk[4], wv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { wq[i] = WF(G::F_QKV + i); wk[i] = WK(G::F_QKV + 4 + i); wv[i] = WK(G::F_QKV + 8 + i); }
+#pragma unroll 1
+            for (int jj = 0; jj < 4; ++jj) {
+                const int j = 4 * pw + jj;
+                f32x16 x0;
+                load_rows(x0, tokoff_of(j));
+                u32x4 xh[2], xl[2];
+                layernorm_frags(x0, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+                f32x16 acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) acc = mma3(wq[2 * s], wq[2 * s + 1], xh[s], xl[s], acc);
+                float t[16];
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = acc[i];
+                // Q fragments rotate through the register array (a runtime tile loop cannot index registers): after four
+                // rounds qf[0] is tile 4*pw, the order phase B consumes them in
+#pragma unroll
+                for (int q = 0; q < 3; ++q) { qf[q][0] = qf[q + 1][0]; qf[q][1] = qf[q + 1][1]; }
+                qf[3][0] = pack8_f16(t);
+                qf[3][1] = pack8_f16(t + 8);
+                acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) acc = mma3(wk[2 * s], wk[2 * s + 1], xh[s], xl[s], acc);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = acc[i];
+                u32x4* kdst = kimg + ((kvs * 8 + j) * 2) * 64 + lane;
+                kdst[0] = pack8_f16(t);
+                kdst[64] = pack8_f16(t + 8);
+                acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) acc = mma3<false>(xh[s], xl[s], wv[2 * s], wv[2 * s + 1], acc);
+#pragma unroll
+                for (int i = 0; i < 16; ++i) t[i] = acc[i];
+                u32x4* vdst = vimg + (kvs * 16 + 2 * j) * 64 + lane;
+                vdst[0] = pack8_f16(t);
+                vdst[64] = pack8_f16(t + 8);
+            }
+        }
+        __syncthreads();   // K / V^T images of all 256 keys of both streams are complete
+
+        // ---- phase B: per tile attention over 256 keys, projection, LN2, MLP, store ----
+        const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
+        const u32x4* ksrc = kimg + (ws * 16) * 64 + lane;
+        const u32x4* vsrc = vimg + (ws * 16) * 64 + lane;
+#pragma unroll 1
+        for (int jj = 0; jj < 4; ++jj) {
+            const int j = 4 * pw + jj;   // query tile
+            const unsigned tokoff = tokoff_of(j);
+            f32x16 o = zero16;
+            float mrun[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};   // running (f16-rounded) maximum: register a, lane half p = head 2a + p
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                if (rowv && ((j < 4) != (c < 2))) continue;   // the chunk's keys lie across the row seam: probabilities exactly 0
+                // bias tiles of key tiles 2c, 2c+1 against query tile j: table entry kt - j + 7
+                f32x16 bias[2];
+                {
+                    const int d0 = __builtin_amdgcn_readfirstlane(2 * c - j + 7);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int q4 = 0; q4 < 4; ++q4) {
+                            const f32x4 tb = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, lane * 64 + q4 * 16, (int)G::p_bias + (d0 + kt) * 4096, 0));
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) bias[kt][q4 * 4 + e] = tb[e];
+                        }
+                    if (colv) {   // key column (register bit 2) and query column (lane bit 3) on different sides of column 8
+                        const bool qhi = (r & 8) != 0;
+                        const float pen_lo = qhi ? -INFINITY : 0.f, pen_hi = qhi ? 0.f : -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float pen = ((i >> 2) & 1) ? pen_hi : pen_lo;
+                            bias[0][i] += pen; bias[1][i] += pen;
+                        }
+                    }
+                }
+                const u32x4* kc = ksrc + (2 * c) * 2 * 64;
+                const u32x4* vc = vsrc + (4 * c) * 64;
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int s = h >> 2, sub = (h >> 1) & 1;
+                    const bool keep = half1 == ((h & 1) != 0);
+                    const u32x4 ka0 = kc[(0 * 2 + s) * 64], ka1 = kc[(1 * 2 + s) * 64];
+                    u32x4 qm = {0u, 0u, 0u, 0u};
+                    qm[2 * sub] = keep ? qf[0][s][2 * sub] : 0u;
+                    qm[2 * sub + 1] = keep ? qf[0][s][2 * sub + 1] : 0u;
+                    f32x16 s0 = mfma_f16(ka0, qm, bias[0]);
+                    f32x16 s1 = mfma_f16(ka1, qm, bias[1]);
+                    float mx = max3f(s0[0], s0[1], s1[0]);
+                    mx = max3f(mx, s1[1], s0[2]);
+#pragma unroll
+                    for (int i = 3; i < 16; i += 2) mx = max3f(mx, s0[i], s0[i + 1 < 16 ? i + 1 : i]);
+#pragma unroll
+                    for (int i = 2; i < 16; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+                    mx = max_halves(mx);
+                    const float mold = mrun[h >> 1];
+                    const f16 nm = (f16)(-__builtin_fmaxf(mold, mx));
+                    const float mnew = -(float)nm;                      // the shift the second pass really applies
+                    const float alpha = __builtin_amdgcn_exp2f(mold - mnew);   // first chunk: 2^-inf = 0
+                    mrun[h >> 1] = keep ? mnew : mold;
+                    const unsigned nmb = keep ? (unsigned)__builtin_bit_cast(unsigned short, nm) : 0u;
+                    qm[2 * sub + 1] |= nmb << 16;
+                    s0 = mfma_f16(ka0, qm, bias[0]);
+                    s1 = mfma_f16(ka1, qm, bias[1]);
+                    f32x16 t;
+#pragma unroll
+                    for (int ps = 0; ps < 4; ++ps) {
+                        float pe[8];
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) pe[e] = __builtin_amdgcn_exp2f((ps >> 1) ? s1[8 * (ps & 1) + e] : s0[8 * (ps & 1) + e]);
+                        const u32x4 pf = pack8_f16(pe);
+                        const u32x4 va = vc[ps * 64];
+                        t = mfma_f16(va, pf, ps == 0 ? zero16 : t);
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        const int i = 4 * (h >> 1) + e;
+                        o[i] = keep ? __builtin_fmaf(o[i], alpha, t[i]) : o[i];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the next tile's Q fragments move up
+#pragma unroll
+            for (int q = 0; q < 3; ++q) { qf[q][0] = qf[q + 1][0]; qf[q][1] = qf[q + 1][1]; }
+
+            // ---- normalise, output projection + bias + residual ----
+            f32x16 res;
+            W24_FENCE();
+            load_rows(res, tokoff);
+            {
+                float t[16];
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const float inv = __builtin_amdgcn_rcpf(o[4 * a + 3]);
+                    t[4 * a] = o[4 * a] * inv; t[4 * a + 1] = o[4 * a + 1] * inv; t[4 * a + 2] = o[4 * a + 2] * inv;
+                    t[4 * a + 3] = 1.0f;
+                }
+                u32x4 oh[2], ol[2];
+                split8(t, oh[0], ol[0]);
+                split8(t + 8, oh[1], ol[1]);
+                W24_FENCE();
+#pragma unroll
+                for (int s = 0; s < 2; ++s) res = mma3(WF(G::F_P + 2 * s), WF(G::F_P + 2 * s + 1), oh[s], ol[s], res);
+            }
+            // ---- LN2, MLP ----
+            {
+                u32x4 xh[2], xl[2];
+                layernorm_frags(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+#pragma unroll
+                for (int tI = 0; tI < G::NT1; ++tI) {
+                    W24_FENCE();
+                    f32x16 acc = zero16;
+#pragma unroll
+                    for (int s = 0; s < 2; ++s)
+                        acc = mma3(WF(G::F_W1 + 4 * tI + 2 * s), WF(G::F_W1 + 4 * tI + 2 * s + 1), xh[s], xl[s], acc);
+                    float e[16];
+#pragma unroll
+                    for (int i = 0; i < 16; ++i) {
+                        const float u = acc[i];
+                        if constexpr (W24_MED3) {
+                            const float L = __builtin_fmaf(__builtin_amdgcn_exp2f(u), kLog2e, -kLog2e);
+                            e[i] = __builtin_amdgcn_fmed3f(u, L, 0.f);
+                        } else {
+                            e[i] = u > 0.f ? u : __builtin_amdgcn_exp2f(u * kLog2e) - 1.0f;
+                        }
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        const int u = 2 * tI + s2;
+                        if (u < G::KU) {
+                            u32x4 hh, hl;
+                            split8(e + 8 * s2, hh, hl);
+                            W24_FENCE();
+                            res = mma3(WF(G::F_W2 + 2 * u), WF(G::F_W2 + 2 * u + 1), hh, hl, res);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+                if constexpr (!G::ONES_H) {
+#pragma unroll
+                    for (int a = 0; a < 3; ++a) {
+                        const float4 b2 = *reinterpret_cast<const float4*>(vec + G::V_B2 + 4 * a);
+                        res[4 * a] += b2.x; res[4 * a + 1] += b2.y; res[4 * a + 2] += b2.z; res[4 * a + 3] += b2.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 3; ++a) {
+                const f32x4 v = {res[4 * a], res[4 * a + 1], res[4 * a + 2], res[4 * a + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, tokoff, 32 * a, 0);
+            }
+        }
+        __syncthreads();   // every wave is done with the K / V^T images: the next window may overwrite them
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // weight packing: fp32 nn.Parameter tensors -> fragment-major split-bf16 images with their k columns in rho order
 // ---------------------------------------------------------------------------------------------------------------
 struct Pack24Args {
@@ -586,6 +864,17 @@ __global__ __launch_bounds__(256) void pack24_kernel(Pack24Args a) {
     }
     // relative-position bias (a001:113-144), exp2 units, the S^T accumulator registers of each lane: [query block][lane][key tile][register]
     float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    if (a.ws == 16) {
+        // 16x16 windows: one S^T tile per distance d = kt - qb + 7 between the key tile and the query tile (a tile = two window
+        // rows): [d][lane][reg], key = rho(reg, lane half), query = lane & 31, row = index >> 4, column = index & 15
+        for (int i = gtid; i < 15 * 64 * 16; i += gsz) {
+            const int reg = i & 15, lane = (i >> 4) & 63, d = i >> 10;
+            const int key = rho(reg, lane >> 5), q = lane & 31;
+            const int dy = 2 * (d - 7) + (key >> 4) - (q >> 4), dx = (key & 15) - (q & 15);
+            bm[i] = (dy >= -15 && dy <= 15) ? p.attn.bias_table[(dy + 15) * 31 + (dx + 15)] * kLog2e : 0.f;
+        }
+        return;
+    }
     for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
         const int reg = i & 15, kt = (i >> 4) & 1, lane = (i >> 5) & 63, qb = i >> 11;
         const int key = 32 * kt + rho(reg, lane >> 5), q = 32 * qb + (lane & 31);
@@ -610,11 +899,12 @@ int num_cus24() {
 
 bool win24_supported(const swf_block_desc& d) {
     return d.attn.channels == 24 && d.attn.heads == 8 && d.attn.head_dim == 3 && d.attn.win_h == d.attn.win_w &&
-           (d.attn.win_h == 8 || d.attn.win_h == 7) && (d.hidden == 96 || d.hidden == 4);
+           (d.attn.win_h == 8 || d.attn.win_h == 7 || d.attn.win_h == 16) && (d.hidden == 96 || d.hidden == 4);
 }
 
 size_t win24_packed_bytes(const swf_block_desc& d) {
     if (!win24_supported(d)) return 0;
+    if (d.attn.win_h == 16) return align_up(d.hidden == 96 ? G24<96>::p_total16 : G24<4>::p_total16, 256);
     return align_up(d.hidden == 96 ? G24<96>::p_total : G24<4>::p_total, 256);
 }
 
@@ -644,6 +934,18 @@ int launch_win24(const swf_block_desc& d, const void* packed_x, const void* pack
     a.warm_bytes = (int)(next_bytes ? next_bytes : win24_packed_bytes(d));
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
     const int nwin = B * (H / wsd) * (W / wsd);
+    if (wsd == 16) {   // 65 KB of LDS per workgroup: dynamic allocation, two workgroups per CU
+        constexpr int lds = (int)G24<96>::l_total16;
+        static hipError_t attr_err = [] {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window24w16_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(&window24w16_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        }();
+        if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window24w16): %s", hipGetErrorString(attr_err));
+        const int grid16 = std::min(nwin, 2 * num_cus24());
+        if (d.hidden == 96) hipLaunchKernelGGL((window24w16_kernel<96>), dim3(grid16), dim3(256), lds, stream, a);
+        else hipLaunchKernelGGL((window24w16_kernel<4>), dim3(grid16), dim3(256), lds, stream, a);
+        return check_launch("window24w16");
+    }
     const int grid = std::min(nwin, W24_WAVES * num_cus24());   // resident workgroups per CU (register-limited)
     if (wsd == 8) {
         if (d.hidden == 96) hipLaunchKernelGGL((window24_kernel<96, 8>), dim3(grid), dim3(256), 0, stream, a);

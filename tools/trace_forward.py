@@ -16,12 +16,13 @@ def run():
     entry.build()
     from swin_unet_image_fusion_amd import CONFIGS, MyModel, load_recipe_into, synthetic_pair
     torch.set_grad_enabled(False)
-    cfg = CONFIGS["win8"]
+    cfg = CONFIGS[os.environ.get("TRACE_CONFIG", "win8")]   # TRACE_CONFIG / TRACE_BATCH / TRACE_SIZE: other BASELINE configs
     model = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True))).eval()
     load_recipe_into(model, seed=0)
     model.to("cuda:0")
     model.precision = "fast"
-    ir, vis = synthetic_pair(16, 256, 256)
+    size = int(os.environ.get("TRACE_SIZE", "256"))
+    ir, vis = synthetic_pair(int(os.environ.get("TRACE_BATCH", "16")), size, size)
     ir, vis = torch.from_numpy(ir).cuda(), torch.from_numpy(vis).cuda()
     for _ in range(4):
         model(ir, vis)
