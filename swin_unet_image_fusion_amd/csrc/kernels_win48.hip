@@ -150,9 +150,13 @@ __device__ __forceinline__ void attention48(const u32x4* ksrc, const u32x4* vsrc
     }
 }
 
-template <int HID>
+// WS = window side, 8 or 7 (the reference's default, A000_CONFIG.py:55).  A 7x7 window runs on the same 8x8 token grid, as in
+// kernels_win24.hip: the 15 padding tokens load zeros and store nothing (an offset beyond the buffer descriptor's range) and
+// carry -inf in the packed bias matrix as keys; the shift seam sits at WS - WS/2 = 4 for both sizes.
+template <int HID, int WS>
 __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args) {
     using G = G48<HID>;
+    static_assert(WS == 7 || WS == 8, "window side");
     __shared__ __attribute__((aligned(16))) char smem[G::l_total];
     u32x4* kimg = reinterpret_cast<u32x4*>(smem + G::l_k);   // [stream][key tile][vch tile][k-step][lane]
     u32x4* vimg = reinterpret_cast<u32x4*>(smem + G::l_v);   // [stream][vch tile][pv-step][lane]
@@ -160,9 +164,9 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ws = wave >> 1, qb = wave & 1, r = lane & 31, hf = lane >> 5;
-    const int H = args.H, W = args.W, nwx = W >> 3, nwy = H >> 3, npi = nwx * nwy;
+    const int H = args.H, W = args.W, nwx = W / WS, nwy = H / WS, npi = nwx * nwy;
     const int nwin = args.B * npi;
-    const int sh = args.shift ? 4 : 0;
+    const int sh = args.shift ? WS / 2 : 0;
     const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
 
     for (int i = tid; i < 2 * G::VSTREAM; i += 256)
@@ -187,10 +191,12 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
         SWF_WF_FENCE();
         const int b = win / npi, wrem = win - b * npi;
         const int wy = wrem / nwx, wx = wrem - wy * nwx;
-        int oy = wy * 8 + 4 * qb + (r >> 3) + sh, ox = wx * 8 + (r & 7) + sh;
+        const int ty = 4 * qb + (r >> 3), tx = r & 7;
+        int oy = wy * WS + ty + sh, ox = wx * WS + tx + sh;
         oy = oy >= H ? oy - H : oy;
         ox = ox >= W ? ox - W : ox;
-        const unsigned tokoff = (unsigned)((((b * H + oy) * W + ox) * 48 + 4 * hf) * 4);   // byte offset of the lane's first float4
+        // byte offset of the lane's first float4; padding tokens of a 7x7 window point beyond the buffer (reads 0, stores dropped)
+        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 48 + 4 * hf) * 4) : 0x80000000u;
         // the lane's 24 channels: tile 0 registers 4a.. = channels 8a+4hf.. (a < 4), tile 1 registers 4a.. = channels 32+8a+4hf.. (a < 2)
         auto load_rows = [&](f32x16& t0, f32x16& t1) {
 #pragma unroll
@@ -397,6 +403,7 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
 struct Pack48Args {
     swf_block_stream_params p[2];
     char* dst[2];
+    int ws;   // window side (7 or 8)
 };
 
 // k index (input channel / virtual channel / hidden unit offset) of element e of k-step s in lane half hf, for an operand
@@ -474,8 +481,11 @@ __global__ __launch_bounds__(256) void pack48_kernel(Pack48Args a) {
     for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
         const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, kt = (i >> 10) & 1, qb = i >> 11;
         const int key = 32 * kt + rho(4 * a4 + j, lane >> 5), q = 32 * qb + (lane & 31);
-        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7;
-        bm[i] = p.attn.bias_table[(ky - qy + 7) * 15 + (kx - qx + 7)] * kLog2e;
+        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7, ws = a.ws, tw = 2 * ws - 1;
+        float v = 0.f;
+        if (ky >= ws || kx >= ws) v = -INFINITY;   // padding token of a 7x7 window as key: probability 0
+        else if (qy < ws && qx < ws) v = p.attn.bias_table[(ky - qy + ws - 1) * tw + (kx - qx + ws - 1)] * kLog2e;
+        bm[i] = v;
     }
 }
 
@@ -491,7 +501,7 @@ int num_cus48() {
 }  // namespace
 
 bool win48_supported(const swf_block_desc& d) {
-    return d.attn.channels == 48 && d.attn.heads == 8 && d.attn.head_dim == 6 && d.attn.win_h == 8 && d.attn.win_w == 8 &&
+    return d.attn.channels == 48 && d.attn.heads == 8 && d.attn.head_dim == 6 && d.attn.win_h == d.attn.win_w && (d.attn.win_h == 8 || d.attn.win_h == 7) &&
            (d.hidden == 192 || d.hidden == 96);
 }
 
@@ -506,6 +516,7 @@ int pack_win48(const swf_block_desc& d, const swf_block_stream_params& px, const
     Pack48Args a;
     a.p[0] = px; a.p[1] = py;
     a.dst[0] = static_cast<char*>(packed_x); a.dst[1] = static_cast<char*>(packed_y);
+    a.ws = d.attn.win_h;
     if (d.hidden == 192) hipLaunchKernelGGL((pack48_kernel<192>), dim3(64, 2), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((pack48_kernel<96>), dim3(64, 2), dim3(256), 0, stream, a);
     return check_launch("pack_win48");
@@ -514,7 +525,8 @@ int pack_win48(const swf_block_desc& d, const swf_block_stream_params& px, const
 int launch_win48(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,
                  float* x_out, float* y_out, int B, int H, int W, hipStream_t stream, const void* next_packed_x,
                  const void* next_packed_y, size_t next_bytes) {
-    if (!win48_supported(d) || H % 8 || W % 8) return fail(SWF_ERR_UNSUPPORTED, "win48: shape not covered");
+    const int wsd = d.attn.win_h;
+    if (!win48_supported(d) || H % wsd || W % wsd) return fail(SWF_ERR_UNSUPPORTED, "win48: shape not covered");
     if ((int64_t)B * H * W * 48 * 4 >= (int64_t(1) << 31)) return fail(SWF_ERR_UNSUPPORTED, "win48: a stream of %d x %d x %d tokens exceeds the 2 GB buffer window", B, H, W);
     Win48Args a;
     a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
@@ -523,10 +535,15 @@ int launch_win48(const swf_block_desc& d, const void* packed_x, const void* pack
     if (!a.warm[1]) a.warm[0] = nullptr;
     a.warm_bytes = (int)(next_bytes ? next_bytes : win48_packed_bytes(d));
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
-    const int nwin = B * (H / 8) * (W / 8);
+    const int nwin = B * (H / wsd) * (W / wsd);
     const int grid = std::min(nwin, W48_WAVES * num_cus48());
-    if (d.hidden == 192) hipLaunchKernelGGL((window48_kernel<192>), dim3(grid), dim3(256), 0, stream, a);
-    else hipLaunchKernelGGL((window48_kernel<96>), dim3(grid), dim3(256), 0, stream, a);
+    if (wsd == 8) {
+        if (d.hidden == 192) hipLaunchKernelGGL((window48_kernel<192, 8>), dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((window48_kernel<96, 8>), dim3(grid), dim3(256), 0, stream, a);
+    } else {
+        if (d.hidden == 192) hipLaunchKernelGGL((window48_kernel<192, 7>), dim3(grid), dim3(256), 0, stream, a);
+        else hipLaunchKernelGGL((window48_kernel<96, 7>), dim3(grid), dim3(256), 0, stream, a);
+    }
     return check_launch("window48");
 }
 

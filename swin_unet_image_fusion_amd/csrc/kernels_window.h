@@ -26,14 +26,14 @@ int launch_window_block(const swf_block_desc& d, const void* packed_x, const voi
 // Touch a buffer from every XCD so that it is L2-resident for the next launch (a fused stage that follows a deep-level stage).
 int launch_l2_warm(const void* p, size_t bytes, hipStream_t stream);
 
-// MFMA attention core on projection buffers (8x8 windows, head_dim in {3,6,12,24,48}); same contract as
+// MFMA attention core on projection buffers (8x8 or 7x7 windows — `win` —, head_dim in {3,6,12,24,48}); same contract as
 // launch_attn_core of the exact tier, fast-tier arithmetic (bf16 QK^T, fp16 PV, fp32 softmax).
 bool attn_core_mfma_supported(int wh, int ww, int head_dim);
 int launch_attn_core_mfma(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
                           const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
                           int heads, int head_dim, int shift, hipStream_t stream, unsigned short* const* O_hi = nullptr,
                           unsigned short* const* O_lo = nullptr, const unsigned short* const* Q16 = nullptr,
-                          const unsigned short* const* K16 = nullptr, const unsigned short* const* V16 = nullptr);
+                          const unsigned short* const* K16 = nullptr, const unsigned short* const* V16 = nullptr, int win = 8);
 // Q16 / K16 / V16 non-null (head_dim % 4 == 0): the operands come in the core's own formats — Q f16 pre-scaled by
 // d^-0.5 * log2(e), K f16, V f16 (row strides ldq / ldk / ldv in elements) — as written by the deep-level Q/K/V GEMM
 // epilogue (SP_EPI_QKV16); Q / K / V are then ignored.

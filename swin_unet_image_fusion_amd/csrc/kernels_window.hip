@@ -775,10 +775,12 @@ struct AttnMfmaArgs {
     int ldq, ldk, ldv, ldo, B, H, W, heads, shift;
 };
 
-template <int D>
+template <int D, int WS>
 __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
-    // one workgroup = (window, head, stream); wave = 32-query block
-    constexpr int T = 64, WH = 8, WW = 8, QS = cround(D, 8), QKS = cceil(D, 16), MT = cceil(D, 32), TW = 2 * WW - 1, VRS = T + 8;
+    // one workgroup = (window, head, stream); wave = 32-query block.  WS = 7 (the reference's default window, A000_CONFIG.py:55)
+    // runs on the same 8x8 token grid: the 15 padding tokens are staged as zeros, carry probability 0 as keys and are not stored
+    static_assert(WS == 7 || WS == 8, "window side");
+    constexpr int T = 64, WH = WS, WW = WS, QS = cround(D, 8), QKS = cceil(D, 16), MT = cceil(D, 32), TW = 2 * WW - 1, VRS = T + 8;
     constexpr int VEC = (D % 4 == 0) ? 4 : ((D % 2 == 0) ? 2 : 1);   // floats per global load of a head's channel run
     constexpr int CPT = D / VEC, NCHUNK = T * CPT, NIT = cceil(NCHUNK, 128);
     __shared__ __attribute__((aligned(16))) f16 qimg[T * QS];
@@ -809,11 +811,14 @@ __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
                 const int e = tid + it * 128;
                 if (e < NCHUNK) {
                     const int tok = e / CPT, c0 = (e % CPT) * VEC;
-                    const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
-                    const int64_t t = ((int64_t)b * H + oy) * W + ox;
-                    q2[it] = *reinterpret_cast<const uint2*>(a.Q16[p] + t * a.ldq + head * D + c0);
-                    k2[it] = *reinterpret_cast<const uint2*>(a.K16[p] + t * a.ldk + head * D + c0);
-                    v2[it] = *reinterpret_cast<const uint2*>(a.V16[p] + t * a.ldv + head * D + c0);
+                    q2[it] = k2[it] = v2[it] = make_uint2(0u, 0u);
+                    if ((tok >> 3) < WS && (tok & 7) < WS) {
+                        const int oy = (wy * WH + (tok >> 3) + sh) % H, ox = (wx * WW + (tok & 7) + sw) % W;
+                        const int64_t t = ((int64_t)b * H + oy) * W + ox;
+                        q2[it] = *reinterpret_cast<const uint2*>(a.Q16[p] + t * a.ldq + head * D + c0);
+                        k2[it] = *reinterpret_cast<const uint2*>(a.K16[p] + t * a.ldk + head * D + c0);
+                        v2[it] = *reinterpret_cast<const uint2*>(a.V16[p] + t * a.ldv + head * D + c0);
+                    }
                 }
             }
 #pragma unroll
@@ -840,7 +845,10 @@ __global__ __launch_bounds__(128) void attn_core_mfma_kernel(AttnMfmaArgs a) {
         const int e = tid + it * 128;
         if (e < NCHUNK) {
             const int tok = e / CPT, c0 = (e % CPT) * VEC;
-            const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
+#pragma unroll
+            for (int j = 0; j < VEC; ++j) qv[it][j] = kv[it][j] = vv[it][j] = 0.f;
+            if ((tok >> 3) >= WS || (tok & 7) >= WS) continue;   // padding token of a 7x7 window
+            const int oy = (wy * WH + (tok >> 3) + sh) % H, ox = (wx * WW + (tok & 7) + sw) % W;
             const int64_t t = ((int64_t)b * H + oy) * W + ox;
             const float* qp = a.Q[p] + t * a.ldq + head * D + c0;
             const float* kp = a.K[p] + t * a.ldk + head * D + c0;
@@ -889,10 +897,11 @@ staged:
 #pragma unroll
         for (int i = 0; i < 16; ++i) {
             const int ky = 4 * kt + (i >> 2), kx = (i & 3) + 4 * hf;
-            float v = tab[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
+            const bool pad_k = ky >= WS || kx >= WS, pad_q = qy >= WS || qx >= WS;
+            float v = (pad_k || pad_q) ? 0.f : tab[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
             const bool my = last_row && ((ky >= WH - WH / 2) != (qy >= WH - WH / 2));
             const bool mx = last_col && ((kx >= WW - WW / 2) != (qx >= WW - WW / 2));
-            acc[kt][i] = (my || mx) ? -1e10f * kLog2e : v;
+            acc[kt][i] = (my || mx || pad_k) ? -1e10f * kLog2e : v;
         }
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
@@ -945,7 +954,8 @@ staged:
             }
         }
     const float inv = 1.0f / l;
-    const int oy = (wy * WH + q / WW + sh) % H, ox = (wx * WW + q % WW + sw) % W;
+    if (qy >= WS || qx >= WS) return;   // padding token: nothing to store (no barrier follows)
+    const int oy = (wy * WH + qy + sh) % H, ox = (wx * WW + qx + sw) % W;
     const int64_t ooff = (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
     if constexpr (D % 4 == 0) {
         if (a.Ohi[p]) {   // split-bf16 planes for the deep-level projection GEMM (kernels_deep.h)
@@ -989,9 +999,10 @@ staged:
 }
 
 template <int D>
-static int launch_attn_mfma_t(const AttnMfmaArgs& a, int nprob, hipStream_t stream) {
-    const int nwin = a.B * (a.H / 8) * (a.W / 8);
-    hipLaunchKernelGGL((attn_core_mfma_kernel<D>), dim3(nwin, a.heads, nprob), dim3(128), 0, stream, a);
+static int launch_attn_mfma_t(const AttnMfmaArgs& a, int ws, int nprob, hipStream_t stream) {
+    const int nwin = a.B * (a.H / ws) * (a.W / ws);
+    if (ws == 8) hipLaunchKernelGGL((attn_core_mfma_kernel<D, 8>), dim3(nwin, a.heads, nprob), dim3(128), 0, stream, a);
+    else hipLaunchKernelGGL((attn_core_mfma_kernel<D, 7>), dim3(nwin, a.heads, nprob), dim3(128), 0, stream, a);
     return check_launch("attn_core_mfma");
 }
 
@@ -1195,15 +1206,16 @@ bool attn_core_mfma16_supported(int wh, int ww, int head_dim) {
 }
 
 bool attn_core_mfma_supported(int wh, int ww, int head_dim) {
-    return wh == 8 && ww == 8 && (head_dim == 3 || head_dim == 6 || head_dim == 12 || head_dim == 24 || head_dim == 48);
+    return wh == ww && (wh == 8 || wh == 7) && (head_dim == 3 || head_dim == 6 || head_dim == 12 || head_dim == 24 || head_dim == 48);
 }
 
 int launch_attn_core_mfma(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
                           const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
                           int heads, int head_dim, int shift, hipStream_t stream, unsigned short* const* O_hi,
                           unsigned short* const* O_lo, const unsigned short* const* Q16, const unsigned short* const* K16,
-                          const unsigned short* const* V16) {
+                          const unsigned short* const* V16, int win) {
     AttnMfmaArgs a{};
+    if ((win != 7 && win != 8) || H % win || W % win) return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: window %d on a %d x %d map", win, H, W);
     if (Q16 && (head_dim % 4 || ldq % 4 || ldk % 4 || ldv % 4)) return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: 16-bit operands need head_dim and strides %% 4 == 0");
     if (O_hi && head_dim % 4) return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: split-plane output needs head_dim %% 4 == 0");
     for (int i = 0; i < nprob; ++i) {
@@ -1213,11 +1225,11 @@ int launch_attn_core_mfma(const float* const* Q, const float* const* K, const fl
     }
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.W = W; a.heads = heads; a.shift = shift;
     switch (head_dim) {
-        case 3: return launch_attn_mfma_t<3>(a, nprob, stream);
-        case 6: return launch_attn_mfma_t<6>(a, nprob, stream);
-        case 12: return launch_attn_mfma_t<12>(a, nprob, stream);
-        case 24: return launch_attn_mfma_t<24>(a, nprob, stream);
-        case 48: return launch_attn_mfma_t<48>(a, nprob, stream);
+        case 3: return launch_attn_mfma_t<3>(a, win, nprob, stream);
+        case 6: return launch_attn_mfma_t<6>(a, win, nprob, stream);
+        case 12: return launch_attn_mfma_t<12>(a, win, nprob, stream);
+        case 24: return launch_attn_mfma_t<24>(a, win, nprob, stream);
+        case 48: return launch_attn_mfma_t<48>(a, win, nprob, stream);
     }
     return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: head_dim %d", head_dim);
 }
@@ -1360,8 +1372,8 @@ static bool dims_match(const swf_block_desc& d, int C, int HID) {
 bool window_block_supported(const swf_block_desc& d, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return false;
     if (use_win24(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 24 * 4 < (int64_t(1) << 31);
+    if (use_win48(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 48 * 4 < (int64_t(1) << 31);
     if (H % 8 || W % 8) return false;
-    if (use_win48(d)) return (int64_t)B * H * W * 48 * 4 < (int64_t(1) << 31);
 #define X(C, HID) if (dims_match(d, C, HID)) return true;
     SWF_WINDOW_SHAPES(X)
 #undef X

@@ -98,7 +98,8 @@ static int attention_generic(const swf_attn_desc& d, int nstream, const swf_attn
         const float* kk[2] = {qkv[0][1], qkv[1][1]};
         const float* vv[2] = {qkv[0][2], qkv[1][2]};
         const float* tt[2] = {prm[0]->bias_table, nstream == 2 ? prm[1]->bias_table : nullptr};
-        SWF_TRY(launch_attn_core_mfma(qq, kk, vv, o, tt, nstream, HD, HD, HD, HD, B, H, W, d.heads, d.head_dim, d.shift, stream));
+        SWF_TRY(launch_attn_core_mfma(qq, kk, vv, o, tt, nstream, HD, HD, HD, HD, B, H, W, d.heads, d.head_dim, d.shift, stream, nullptr, nullptr,
+                                      nullptr, nullptr, nullptr, d.win_h));
     } else {
         AttnCoreBatch ab{};
         for (int s = 0; s < nstream; ++s) ab.p[s] = AttnCoreProb{qkv[s][0], qkv[s][1], qkv[s][2], o[s], prm[s]->bias_table};
@@ -318,7 +319,7 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         const bf16_raw* vv[2] = {qkv[0][2], qkv[1][2]};
         const float* tt[2] = {pp[0]->attn.bias_table, nstream == 2 ? pp[1]->attn.bias_table : nullptr};
         SWF_TRY(launch_attn_core_mfma(nullptr, nullptr, nullptr, nullptr, tt, nstream, HD, HD, HD, HD, B, H, W, desc->attn.heads,
-                                      desc->attn.head_dim, desc->attn.shift, stream, o_hi, o_lo, qq, kk, vv));
+                                      desc->attn.head_dim, desc->attn.shift, stream, o_hi, o_lo, qq, kk, vv, desc->attn.win_h));
     }
     SpGemmBatch gp{};
     gp.scratch = sk; gp.scratch_floats = sk_floats;

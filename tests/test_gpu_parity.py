@@ -462,6 +462,37 @@ def test_basic_block_wide_vs_oracle(case, precision):
     assert torch.equal(ox, ox2) and torch.equal(oy, oy2)
 
 
+_WIN7 = [  # 7x7 windows (the reference's default, A000_CONFIG.py:55) at every level width: C, heads, d, hidden, (B,H,W), shift, cross
+    (24, 8, 3, 96, (2, 14, 21), True, True),
+    (48, 8, 6, 192, (2, 14, 21), True, True),
+    (48, 8, 6, 96, (1, 21, 14), False, False),
+    (96, 8, 12, 384, (1, 14, 14), True, True),
+    (96, 8, 12, 192, (2, 7, 14), True, False),
+    (192, 8, 24, 768, (2, 14, 14), True, True),
+    (192, 8, 24, 384, (1, 7, 7), False, True),
+    (384, 8, 48, 1536, (2, 7, 7), True, True),      # one window per map: the shift mask covers most of the score tile
+    (384, 8, 48, 768, (1, 14, 7), True, False),
+]
+
+
+@pytest.mark.parametrize("case", _WIN7, ids=[f"C{c[0]}_hid{c[3]}_s{int(c[5])}c{int(c[6])}" for c in _WIN7])
+def test_basic_block_window7_fast_vs_oracle(case):
+    c, nh, d, hid, shape, shift, cross = case
+    b, h, w = shape
+    m = BasicBlock(c, nh, d, (7, 7), shift, True, cross, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
+    load_recipe_into(m, seed=23, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, y = G.randn((b, c, h, w), 611), G.randn((b, c, h, w), 612)
+    rx, ry = O.basic_block(sd, "", x, y, cross=cross, shift=shift, num_heads=nh, dims_per_head=d, window_size=(7, 7))
+    m.to(DEV)
+    m.precision = "fast"
+    ox, oy = m(x.to(DEV), y.to(DEV))
+    _close(ox, rx, TOL_FAST_L2, TOL_FAST_MAX)
+    _close(oy, ry, TOL_FAST_L2, TOL_FAST_MAX)
+    ox2, oy2 = m(x.to(DEV), y.to(DEV))
+    assert torch.equal(ox, ox2) and torch.equal(oy, oy2)
+
+
 def test_block_prepack_matches_per_call_pack():
     """swf_basic_block_pack + swf_basic_block_fwd_packed == swf_basic_block_fwd (same kernel, weights packed once)."""
     import ctypes as C
