@@ -118,9 +118,12 @@ __device__ unsigned long long qa_probe[8];
 #define QA_STAMP(i) do { } while (0)
 #endif
 
-template <int C>
+// WS = window side, 8 or 7 (the reference's default) on the same 8x8 token grid: a padding token stages a neighbouring token's
+// row (any finite row serves), carries -inf in the packed bias matrix as key, and is not stored.
+template <int C, int WS>
 __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
     using G = QA<C>;
+    static_assert(WS == 7 || WS == 8, "window side");
     constexpr int KS = G::KS, XS = G::XS;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     u32x4* kimg = reinterpret_cast<u32x4*>(smem + G::l_k);   // [head in group][key tile][k-step][lane]
@@ -128,16 +131,16 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int hl = wave >> 1, tt = wave & 1, r = lane & 31, hf = lane >> 5;
-    const int H = a.H, W = a.W, nwx = W >> 3, nwy = H >> 3, npi = nwx * nwy;
+    const int H = a.H, W = a.W, nwx = W / WS, nwy = H / WS, npi = nwx * nwy;
     const int win = blockIdx.x, st = blockIdx.y, hg = blockIdx.z, head = hg * G::HG + hl;
     const int b = win / npi, wrem = win - b * npi, wy = wrem / nwx, wx = wrem - wy * nwx;
-    const int sh = a.shift ? 4 : 0;
+    const int sh = a.shift ? WS / 2 : 0;
     const bool cross = a.cross && a.nstream == 2;
     const int kvs = cross ? 1 - st : st;
 
     // image token index of window token t (cyclic shift = index arithmetic, a001:442-445)
     auto tok_index = [&](int t) {
-        int oy = wy * 8 + (t >> 3) + sh, ox = wx * 8 + (t & 7) + sh;
+        int oy = wy * WS + (t >> 3) + sh, ox = wx * WS + (t & 7) + sh;
         oy = oy >= H ? oy - H : oy;
         ox = ox >= W ? ox - W : ox;
         return (b * H + oy) * W + ox;
@@ -311,7 +314,9 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
     float den, unused;
     halves(t[12], den, unused);
     const float inv = __builtin_amdgcn_rcpf(den);
+    auto padding = [](int t) { return WS != 8 && ((t >> 3) >= WS || (t & 7) >= WS); };
     if (a.part[0][st] == nullptr) {   // O leaves as split-bf16 planes (the projection GEMM's input)
+        if (padding(32 * qt + r)) return;   // (no barrier follows on this path)
         const int64_t orow = (int64_t)tok_index(32 * qt + r) * (G::HEADS * G::D) + head * G::D + 4 * hf;
         bf16* oh = a.o_hi[st] + orow;
         bf16* ol = a.o_lo[st] + orow;
@@ -373,14 +378,15 @@ __global__ __launch_bounds__(512, 2) void qkv_attn_kernel(QaDev a) {
                 for (int f = 0; f < G::HG * 4; ++f) wp[f] = PFRAG(tile + G::HG, f);
             }
 #pragma unroll
-            for (int i = 0; i < 16; ++i) pout[tokrow[i] + 32 * tile + r] = acc[i];
+            for (int i = 0; i < 16; ++i)
+                if (!padding(32 * tt + rho(i, hf))) pout[tokrow[i] + 32 * tile + r] = acc[i];
         }
     }
     QA_STAMP(5);
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-struct QaPackArgs { swf_attn_params p; char* dst; };
+struct QaPackArgs { swf_attn_params p; char* dst; int ws; };
 
 template <int C>
 __global__ __launch_bounds__(256) void qa_pack_kernel(QaPackArgs a) {
@@ -424,32 +430,38 @@ __global__ __launch_bounds__(256) void qa_pack_kernel(QaPackArgs a) {
     for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
         const int lane = i & 63, reg = (i >> 6) & 15, kt = (i >> 10) & 1, qt = i >> 11;
         const int key = 32 * kt + rho(reg, lane >> 5), q = 32 * qt + (lane & 31);
-        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7;
-        bm[i] = a.p.bias_table[(ky - qy + 7) * 15 + (kx - qx + 7)] * kLog2e;
+        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7, ws = a.ws, tw = 2 * ws - 1;
+        float v = 0.f;
+        if (ky >= ws || kx >= ws) v = -INFINITY;   // padding token of a 7x7 window as key: probability 0
+        else if (qy < ws && qx < ws) v = a.p.bias_table[(ky - qy + ws - 1) * tw + (kx - qx + ws - 1)] * kLog2e;
+        bm[i] = v;
     }
 }
 
 }  // namespace
 
 bool qkvattn_supported(const swf_block_desc& d) {
-    return d.precision == SWF_PREC_FAST && d.attn.channels == 192 && d.attn.heads == 8 && d.attn.head_dim == 24 && d.attn.win_h == 8 &&
-           d.attn.win_w == 8;
+    return d.precision == SWF_PREC_FAST && d.attn.channels == 192 && d.attn.heads == 8 && d.attn.head_dim == 24 && d.attn.win_h == d.attn.win_w &&
+           (d.attn.win_h == 8 || d.attn.win_h == 7);
 }
 
 size_t qkvattn_packed_bytes(const swf_block_desc& d) { return qkvattn_supported(d) ? align_up(QA<192>::p_total, 256) : 0; }
 
 int pack_qkvattn(const swf_block_desc& d, const swf_block_stream_params& p, void* dst, hipStream_t stream) {
     if (!qkvattn_supported(d)) return fail(SWF_ERR_UNSUPPORTED, "pack_qkvattn: shape not covered");
-    QaPackArgs a{p.attn, static_cast<char*>(dst)};
+    QaPackArgs a{p.attn, static_cast<char*>(dst), d.attn.win_h};
     hipLaunchKernelGGL((qa_pack_kernel<192>), dim3(128), dim3(256), 0, stream, a);
     return check_launch("pack_qkvattn");
 }
 
 int launch_qkvattn(const swf_block_desc& d, const QkvAttnArgs& a, int nstream, hipStream_t stream) {
-    if (!qkvattn_supported(d) || a.H % 8 || a.W % 8) return fail(SWF_ERR_UNSUPPORTED, "qkvattn: shape not covered");
+    const int wsd = d.attn.win_h;
+    if (!qkvattn_supported(d) || a.H % wsd || a.W % wsd) return fail(SWF_ERR_UNSUPPORTED, "qkvattn: shape not covered");
     using G = QA<192>;
-    static hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_kernel<192>),
-                                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::l_total);
+    static hipError_t attr_err = [] {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_kernel<192, 8>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::l_total);
+        return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(&qkv_attn_kernel<192, 7>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::l_total);
+    }();
     if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(qkv_attn): %s", hipGetErrorString(attr_err));
     QaDev dv{};
     for (int s = 0; s < nstream; ++s) {
@@ -461,8 +473,9 @@ int launch_qkvattn(const swf_block_desc& d, const QkvAttnArgs& a, int nstream, h
     if ((dv.part[0][0] != nullptr) != (dv.part[1][0] != nullptr) || (nstream == 2 && (dv.part[0][1] != nullptr) != (dv.part[0][0] != nullptr)))
         return fail(SWF_ERR_NULL, "qkvattn: projection partial buffers must be given for both head groups and streams or not at all");
     dv.B = a.B; dv.H = a.H; dv.W = a.W; dv.shift = a.shift; dv.cross = a.cross; dv.nstream = nstream;
-    const int nwin = a.B * (a.H / 8) * (a.W / 8);
-    hipLaunchKernelGGL((qkv_attn_kernel<192>), dim3(nwin, nstream, 2), dim3(512), G::l_total, stream, dv);
+    const int nwin = a.B * (a.H / wsd) * (a.W / wsd);
+    if (wsd == 8) hipLaunchKernelGGL((qkv_attn_kernel<192, 8>), dim3(nwin, nstream, 2), dim3(512), G::l_total, stream, dv);
+    else hipLaunchKernelGGL((qkv_attn_kernel<192, 7>), dim3(nwin, nstream, 2), dim3(512), G::l_total, stream, dv);
     return check_launch("qkv_attn");
 }
 

@@ -143,6 +143,9 @@ struct WinArgs {
     const char* warm[2];     // packed images of the NEXT block of the stage (or nullptr): touched at the end of this launch
     int B, H, W, shift, cross;
     int warm_bytes;          // bytes of one packed image to touch
+    int ws;                  // window side: 8, or 7 (the reference's default) on the same 8x8 token grid — the 15 padding tokens read
+                             // a neighbouring token (any finite row serves: as keys they carry probability 0 in the packed bias
+                             // matrices, as queries they are never stored)
 };
 
 // ------------------------------------------------------------------------------------------
@@ -294,9 +297,10 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
     if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0) swf_win_probe[10] = wall_clock64();
 #endif
     const int H = args.H, W = args.W;
-    const int nwx = W / G::WW, nwy = H / G::WH;
+    const int wside = args.ws;
+    const int nwx = W / wside, nwy = H / wside;
     const int nwin = args.B * nwx * nwy;
-    const int sh = args.shift ? G::WH / 2 : 0, sw = args.shift ? G::WW / 2 : 0;
+    const int sh = args.shift ? wside / 2 : 0, sw = sh;
 
     auto wsec = [&](int s) -> const char* { return G::WLDS ? smem + G::l_w + s * G::wsec : args.packed[s]; };
     auto wmat = [&](int s, size_t off) { return reinterpret_cast<const bf16*>(wsec(s) + off); };
@@ -346,7 +350,7 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
         const int b = win / (nwx * nwy), wrem = win % (nwx * nwy);
         const int wy = wrem / nwx, wx = wrem % nwx;
         const int tok = (wm0 + tt) * 16 + r16;
-        const int oy = (wy * G::WH + tok / G::WW + sh) % H, ox = (wx * G::WW + tok % G::WW + sw) % W;   // roll(-s): read at (y+s)%H
+        const int oy = (wy * wside + (tok >> 3) + sh) % H, ox = (wx * wside + (tok & 7) + sw) % W;   // roll(-s): read at (y+s)%H
         return (((int64_t)b * H + oy) * W + ox) * C;
     };
 #define SWF_PREFETCH(WIN)                                                                                   \
@@ -737,6 +741,8 @@ __global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : 
 #pragma unroll
         for (int tt = 0; tt < TT; ++tt) {
             float* dst = args.out[ws] + token_base(win, tt);
+            const int tok = (wm0 + tt) * 16 + r16;
+            if ((tok >> 3) >= wside || (tok & 7) >= wside) continue;   // padding token of a 7x7 window
 #pragma unroll
             for (int nt = 0; nt < NTK; ++nt)
                 if (nt * 16 + 4 * g < C) *reinterpret_cast<float4*>(dst + nt * 16 + 4 * g) = res[tt][nt];
@@ -1241,6 +1247,7 @@ struct PackArgs {
     swf_block_stream_params p[2];
     char* dst[2];
     int head_dim;
+    int ws;   // window side (7 or 8)
 };
 
 template <int C_, int HID_>
@@ -1301,14 +1308,16 @@ __global__ __launch_bounds__(256) void pack_block_kernel(PackArgs a) {
     // relative-position bias (a001:113-144) with the shift mask (a001:217-315) folded in, four variants:
     // bit1 = window in the last window row, bit0 = window in the last window column.  Only those windows
     // contain more than one region label; inside them the label bands split at wh - wh/2 (ww - ww/2).
-    constexpr int WH = G::WH, WW = G::WW, TW = 2 * WW - 1;
+    // (7x7 windows on the 8x8 grid: a padding token as key is masked in every variant, as query it gets a zero row)
+    const int WH = a.ws, WW = a.ws, TW = 2 * WW - 1;
     for (int i = gtid; i < 4 * T * T; i += gsz) {
         const int variant = i / (T * T), key = (i / T) % T, q = i % T;
-        const int ky = key / WW, kx = key % WW, qy = q / WW, qx = q % WW;
-        float v = p.attn.bias_table[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
+        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7;
+        const bool pad_k = ky >= WH || kx >= WW, pad_q = qy >= WH || qx >= WW;
+        float v = (pad_k || pad_q) ? 0.f : p.attn.bias_table[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
         const bool my = (variant & 2) && ((ky >= WH - WH / 2) != (qy >= WH - WH / 2));
         const bool mx = (variant & 1) && ((kx >= WW - WW / 2) != (qx >= WW - WW / 2));
-        if (my || mx) v = -1e10f;
+        if (my || mx || pad_k) v = -1e10f;
         reinterpret_cast<float*>(dst + G::p_bias4)[i] = v * kLog2e;
     }
 }
@@ -1365,15 +1374,15 @@ static bool use_win48(const swf_block_desc& d) {
 }
 
 static bool dims_match(const swf_block_desc& d, int C, int HID) {
-    return d.attn.channels == C && d.hidden == HID && d.attn.heads == 8 && d.attn.head_dim * 8 == C && d.attn.win_h == 8 &&
-           d.attn.win_w == 8;
+    return d.attn.channels == C && d.hidden == HID && d.attn.heads == 8 && d.attn.head_dim * 8 == C && d.attn.win_h == d.attn.win_w &&
+           (d.attn.win_h == 8 || d.attn.win_h == 7);
 }
 
 bool window_block_supported(const swf_block_desc& d, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return false;
     if (use_win24(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 24 * 4 < (int64_t(1) << 31);
     if (use_win48(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 48 * 4 < (int64_t(1) << 31);
-    if (H % 8 || W % 8) return false;
+    if (H % d.attn.win_h || W % d.attn.win_w) return false;
 #define X(C, HID) if (dims_match(d, C, HID)) return true;
     SWF_WINDOW_SHAPES(X)
 #undef X
@@ -1401,6 +1410,7 @@ int pack_window_block(const swf_block_desc& d, const swf_block_stream_params& px
     a.p[0] = px; a.p[1] = py;
     a.dst[0] = static_cast<char*>(packed_x); a.dst[1] = static_cast<char*>(packed_y);
     a.head_dim = d.attn.head_dim;
+    a.ws = d.attn.win_h;
 #define X(C, HID) if (dims_match(d, C, HID)) return pack_t<C, HID>(a, stream);
     SWF_WINDOW_SHAPES(X)
 #undef X
@@ -1435,7 +1445,9 @@ int launch_window_block(const swf_block_desc& d, const void* packed_x, const voi
     a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
     a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
-    const int nwin = B * (H / 8) * (W / 8);
+    a.ws = d.attn.win_h;
+    if (H % a.ws || W % a.ws) return fail(SWF_ERR_UNSUPPORTED, "window_block: %d x %d map, window %d", H, W, a.ws);
+    const int nwin = B * (H / a.ws) * (W / a.ws);
 #define X(C, HID) if (dims_match(d, C, HID)) return launch_t<C, HID>(a, nwin, stream);
     SWF_WINDOW_SHAPES(X)
 #undef X
