@@ -436,6 +436,7 @@ _WIDE = [  # C, heads, d, hidden, (B,H,W), shift, cross
     (192, 8, 24, 384, (2, 8, 8), False, True),      # decoder widths (hidden = in_dims * 4): no hidden split / 3 splits
     (384, 8, 48, 768, (1, 8, 8), True, True),
     (192, 8, 24, 768, (2, 16, 16), True, False),    # several 64-token tiles per stream
+    (192, 8, 24, 768, (1, 16, 24), True, True),     # map larger than 16x16: the projection runs as its own GEMM (swf_api.hip: proj_fused)
     (128, 4, 24, 512, (1, 8, 16), True, True),      # heads * d (96) != C: projection K = 96; fused MLP instantiation C = 128
     (256, 8, 24, 1024, (1, 8, 8), False, False),    # heads * d = 192; fused MLP instantiation C = 256
 ]
