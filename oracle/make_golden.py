@@ -199,6 +199,7 @@ MODEL_CASES = [
     ("model_win8_b2_128x192", "win8_4stage", (2, 128, 192), "stress"),      # deepest map 8x12 -> pad to 8x16
     ("model_win8_512_default", "win8", (1, 512, 512), "default"),           # BASELINE config 3 shape, B=1
     ("model_win16_1024_default", "win16", (1, 1024, 1024), "default"),      # BASELINE config 5 shape, B=1
+    ("model_win7_224_default", "win7", (1, 224, 224), "default"),           # the reference's default window (A000:55), every map a multiple of 7
 ]
 
 

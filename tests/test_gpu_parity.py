@@ -278,6 +278,13 @@ def test_full_size_config5_b8_1024_win16():
     _full_size_properties("win16", "model_win16_1024_default", 8, 1024, "fast")
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+def test_full_size_default_window7_b16_224(precision):
+    """The reference's own default configuration (A000_CONFIG.py:55: 7x7 windows) at B=16 224x224: every level on its fused kernel
+    (7x7 windows on the 8x8 token grid); sample 0 against the vector captured from the reference."""
+    _full_size_properties("win7", "model_win7_224_default", 16, 224, precision)
+
+
 def test_reference_checkpoint_to_gpu_forward(tmp_path):
     """a checkpoint in the reference's on-disk format (a016:243-249: model_state + optimizer / scheduler
     state + epoch) -> load_reference_checkpoint (weights_only loader, strict 3139-style key set) -> HIP forward ->
@@ -583,9 +590,10 @@ def test_nonsquare_batch3_vs_oracle(precision):
 
 
 @pytest.mark.parametrize("case", [(24, 3, 96, (1, 32, 48), True, True), (24, 3, 96, (2, 48, 32), False, False), (24, 3, 4, (1, 32, 32), True, False),
+                                  (24, 3, 96, (2, 16, 16), True, True),
                                   (24, 3, 4, (3, 16, 48), False, True), (48, 6, 192, (2, 16, 32), True, False),
                                   (96, 12, 384, (1, 16, 16), True, True), (384, 48, 1536, (1, 16, 16), False, True)],
-                         ids=["C24", "C24_plain_self", "C24_hid4_shift", "C24_hid4_cross", "C48", "C96_onewin", "C384_onewin"])
+                         ids=["C24", "C24_plain_self", "C24_hid4_shift", "C24_onewin", "C24_hid4_cross", "C48", "C96_onewin", "C384_onewin"])
 def test_window16_block_fast_vs_oracle(case):
     """16x16 windows (BASELINE config 5): the fast tier runs the MFMA attention core with online softmax over key
     tiles (256-token windows do not fit a score tile in LDS); checked against the oracle incl. a single-window map,
