@@ -12,6 +12,7 @@
 #include "kernels_window.h"
 #include "kernels_deep.h"
 #include "kernels_patch.h"
+#include "kernels_patchrr.h"
 #include "kernels_mlp.h"
 #include "kernels_qkvattn.h"
 
@@ -446,13 +447,17 @@ static int merge_shapes(int H, int W, int mh, int mw, int wh, int ww, int* Hm, i
 
 static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const float* const* in, float* const* out,
                             int B, int H, int W, int Cin, int Cout, int mh, int mw, int wh, int ww, void* workspace,
-                            size_t workspace_bytes, hipStream_t stream, int fast = 0) {
+                            size_t workspace_bytes, hipStream_t stream, int fast = 0, const void* const* prr = nullptr) {
+    // prr: per-stream packed images of the register-resident kernel (pack_patch_rr; the model path has them) or nullptr
     int Hm, Wm, Ho, Wo;
     SWF_TRY(merge_shapes(H, W, mh, mw, wh, ww, &Hm, &Wm, &Ho, &Wo));
     const int64_t N = (int64_t)B * Ho * Wo;
     const int K = mh * mw * Cin;
-    static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switch
-    if (fast && !no_fused && patch_fused_supported(K, Cout)) {   // one launch: gather -> conv -> LN -> ELU
+    static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switches
+    static const bool no_prr = std::getenv("SWF_NO_PATCH_RR") != nullptr;
+    const bool use_prr = fast && !no_fused && !no_prr && prr && nstream == 2 && patch_rr_supported(0, Cin, Cout, mh, mw) &&
+                         (int64_t)B * H * W * Cin < (int64_t(1) << 31);
+    if (use_prr || (fast && !no_fused && patch_fused_supported(K, Cout))) {   // one launch: gather -> conv -> LN -> ELU
         PatchFusedDesc d{};
         for (int s = 0; s < nstream; ++s) {
             d.in[s] = in[s]; d.out[s] = out[s]; d.skip[s] = nullptr;
@@ -460,6 +465,7 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
         }
         d.decoder = 0; d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.mh = mh; d.mw = mw; d.Hm = Hm; d.Wm = Wm; d.Ho = Ho; d.Wo = Wo;
         d.K = K; d.N = Cout; d.Cout = Cout; d.M = N;
+        if (use_prr) return launch_patch_rr(d, prr, nstream, stream);
         return launch_patch_fused(d, nstream, stream);
     }
     Carver ws(workspace, workspace_bytes);
@@ -486,15 +492,18 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
 static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, const float* const* in,
                               const float* const* skip, float* const* out, int B, int Hp, int Wp, int Hm, int Wm, int Cin,
                               int Cout, int mh, int mw, int Hout, int Wout, void* workspace, size_t workspace_bytes,
-                              hipStream_t stream, int fast = 0) {
+                              hipStream_t stream, int fast = 0, const void* const* prr = nullptr) {
     if (Hm <= 0 || Wm <= 0 || Hm > Hp || Wm > Wp) return fail(SWF_ERR_BAD_SHAPE, "crop %dx%d of %dx%d", Hm, Wm, Hp, Wp);
     if (Hout <= 0 || Wout <= 0 || Hout > Hm * mh || Wout > Wm * mw)
         return fail(SWF_ERR_BAD_SHAPE, "output %dx%d larger than the unmerged map %dx%d", Hout, Wout, Hm * mh, Wm * mw);
     const int64_t N = (int64_t)B * Hm * Wm;
     const int Kz = mh * mw * Cout;
     const bool need_crop = (Hm != Hp) || (Wm != Wp);
-    static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switch
-    if (fast && !no_fused && patch_fused_supported(Cin, Kz)) {   // one launch: crop -> conv -> LN -> scatter -> ELU (+ skip)
+    static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switches
+    static const bool no_prr = std::getenv("SWF_NO_PATCH_RR") != nullptr;
+    const bool use_prr = fast && !no_fused && !no_prr && prr && nstream == 2 && patch_rr_supported(1, Cin, Cout, mh, mw) &&
+                         (int64_t)B * Hp * Wp * Cin < (int64_t(1) << 31);
+    if (use_prr || (fast && !no_fused && patch_fused_supported(Cin, Kz))) {   // one launch: crop -> conv -> LN -> scatter -> ELU (+ skip)
         PatchFusedDesc d{};
         for (int s = 0; s < nstream; ++s) {
             d.in[s] = in[s]; d.out[s] = out[s]; d.skip[s] = skip ? skip[s] : nullptr;
@@ -502,6 +511,7 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
         }
         d.decoder = 1; d.B = B; d.H = Hp; d.W = Wp; d.Cin = Cin; d.mh = mh; d.mw = mw; d.Hm = Hm; d.Wm = Wm; d.Ho = Hout; d.Wo = Wout;
         d.K = Cin; d.N = Kz; d.Cout = Cout; d.M = N;
+        if (use_prr) return launch_patch_rr(d, prr, nstream, stream);
         return launch_patch_fused(d, nstream, stream);
     }
     Carver ws(workspace, workspace_bytes);
@@ -740,6 +750,8 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
 struct PackedPlan {
     size_t enc[SWF_MAX_LEVELS], dec[SWF_MAX_LEVELS], total;
     bool enc_on[SWF_MAX_LEVELS], dec_on[SWF_MAX_LEVELS];
+    // patch layers (register-resident kernel): two per-stream images of penc_b / pdec_b bytes each, 0 = layer not covered
+    size_t penc[SWF_MAX_LEVELS], pdec[SWF_MAX_LEVELS], penc_b[SWF_MAX_LEVELS], pdec_b[SWF_MAX_LEVELS];
 };
 static PackedPlan packed_plan(const swf_model_desc* d) {
     PackedPlan p{};
@@ -755,6 +767,15 @@ static PackedPlan packed_plan(const swf_model_desc* d) {
         bd.precision = SWF_PREC_FAST;
         const size_t pb = block_packed_bytes(bd);
         p.dec_on[j] = pb > 0; p.dec[j] = off; off += 8 * pb;
+    }
+    for (int s = 0; s < d->levels; ++s) {
+        p.penc_b[s] = patch_rr_packed_bytes(0, d->in_dims[s], d->out_dims[s], d->merge_h, d->merge_w);
+        p.penc[s] = off; off += 2 * p.penc_b[s];
+    }
+    for (int j = 0; j < d->levels; ++j) {
+        const int lvl = d->levels - 1 - j;
+        p.pdec_b[j] = patch_rr_packed_bytes(1, d->out_dims[lvl], d->in_dims[lvl], d->merge_h, d->merge_w);
+        p.pdec[j] = off; off += 2 * p.pdec_b[j];
     }
     p.total = off;
     return p;
@@ -1041,6 +1062,21 @@ int swf_model_pack_weights(const swf_model_desc* desc, const float* arena, void*
                 }
             }
         }
+    for (int k = 0; k < desc->levels; ++k) {   // patch layers of the register-resident kernel
+        const int lvl = desc->levels - 1 - k;
+        for (int st = 0; st < 2; ++st) {
+            if (plan.penc_b[k]) {
+                const PatchOff& o = L->enc_patch[k][st];
+                SWF_TRY(pack_patch_rr(0, desc->in_dims[k], desc->out_dims[k], desc->merge_h, desc->merge_w, arena + o.w, arena + o.b, arena + o.g,
+                                      arena + o.bt, base + plan.penc[k] + st * plan.penc_b[k], stream));
+            }
+            if (plan.pdec_b[k]) {
+                const PatchOff& o = L->dec_patch[k][st];
+                SWF_TRY(pack_patch_rr(1, desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, arena + o.w, arena + o.b,
+                                      arena + o.g, arena + o.bt, base + plan.pdec[k] + st * plan.pdec_b[k], stream));
+            }
+        }
+    }
     return SWF_OK;
 }
 
@@ -1074,8 +1110,10 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
     for (int s = 0; s < n; ++s) {
         swf_patch_params pm[2] = {patch_params(L->enc_patch[s][0]), patch_params(L->enc_patch[s][1])};
         const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
+        const void* prr_enc[2] = {packed ? packed + plan.penc[s] : nullptr, packed ? packed + plan.penc[s] + plan.penc_b[s] : nullptr};
         SWF_TRY(patch_merge_impl(pmp, 2, cur, act[s], B, ls[s].Hin, ls[s].Win, desc->in_dims[s], desc->out_dims[s], desc->merge_h,
-                                 desc->merge_w, desc->win_h, desc->win_w, scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST));
+                                 desc->merge_w, desc->win_h, desc->win_w, scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST,
+                                 (packed && plan.penc_b[s]) ? prr_enc : nullptr));
         swf_block_stream_params px[4], py[4];
         for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->enc_blk[s][i][0]); py[i] = make_stream_params(arena, L->enc_blk[s][i][1]); }
         swf_block_desc bd = level_block_desc(desc, s, true);
@@ -1114,9 +1152,10 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
         const float* ins[2] = {act[lvl][0], act[lvl][1]};
         const float* skip[2] = {lvl > 0 ? act[lvl - 1][0] : nullptr, lvl > 0 ? act[lvl - 1][1] : nullptr};
         float* outs[2] = {lvl > 0 ? act[lvl - 1][0] : full[0], lvl > 0 ? act[lvl - 1][1] : full[1]};
+        const void* prr_dec[2] = {packed ? packed + plan.pdec[j] : nullptr, packed ? packed + plan.pdec[j] + plan.pdec_b[j] : nullptr};
         SWF_TRY(patch_unmerge_impl(pmp, 2, ins, lvl > 0 ? skip : nullptr, outs, B, ls[lvl].Ho, ls[lvl].Wo, ls[lvl].Hm, ls[lvl].Wm,
                                    desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, ls[lvl].Hin, ls[lvl].Win,
-                                   scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST));
+                                   scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST, (packed && plan.pdec_b[j]) ? prr_dec : nullptr));
     }
     swf_head_params hp{arena + L->h_c1w, arena + L->h_c1b, arena + L->h_g, arena + L->h_b, arena + L->h_m, arena + L->h_v,
                        arena + L->h_c2w, arena + L->h_c2b};
