@@ -49,6 +49,10 @@ struct G48 {
     static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
     // LDS: K images [stream 2][key tile 2][vch tile 2][k-step 2] x 1 KB, V^T images [stream 2][vch tile 2][pv-step 4] x 1 KB, vectors
     static constexpr size_t l_k = 0, l_v = 16 * 1024, l_vec = 32 * 1024, l_total = l_vec + size_t(2) * VSTREAM * 4;
+    // 16x16 windows (window48w16_kernel): bias tiles by key-tile / query-tile distance, fp32 [distance 15][reg/4 4][lane 64][4];
+    // LDS of ONE stream: K images [key tile 8][vch tile 2][k-step 2] x 1 KB, V^T images [vch tile 2][pv-step 16] x 1 KB, vectors
+    static constexpr size_t p_total16 = p_bias + size_t(15) * 16 * 64 * 4;
+    static constexpr size_t l_k16 = 0, l_v16 = 32 * 1024, l_vec16 = 64 * 1024, l_total16 = l_vec16 + size_t(2) * VSTREAM * 4;
 };
 
 struct Win48Args {
@@ -400,6 +404,313 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 16x16 windows at C = 48 (BASELINE config 5, level 1): one workgroup = (window, stream), four waves, a wave owns two of the
+// eight 32-token tiles.  The K / V^T images of all 256 keys of ONE stream's attention fill 64 KB of LDS (two workgroups per CU):
+// the workgroup computes them itself from the tokens its attention reads — its own stream's, or the other stream's in a cross
+// block (a002:67-82: K and V of attention_x come from LN1_y(y) with attention_x's weights) — so nothing is exchanged between
+// workgroups and only LN1 of those tokens is computed twice in cross blocks.  Phase A: LN1, Q (kept in registers), K, V with
+// each weight-fragment set fetched once for both tiles.  Phase B per tile: online softmax over four chunks of 64 keys (the
+// 8x8 kernel's attention as a chunk, running maximum kept as the f16 value the second S^T pass subtracts; bias tiles by tile
+// distance; row-seam chunks skipped, column seam = register bit 2 against lane bit 3: kernels_win24.hip), projection, LN2, MLP.
+template <int HID>
+__global__ __launch_bounds__(256, 2) void window48w16_kernel(Win48Args args) {
+    using G = G48<HID>;
+    extern __shared__ __attribute__((aligned(16))) char smem48[];
+    u32x4* kimg = reinterpret_cast<u32x4*>(smem48 + G::l_k16);   // [key tile][vch tile][k-step][lane]
+    u32x4* vimg = reinterpret_cast<u32x4*>(smem48 + G::l_v16);   // [vch tile][pv-step][lane]
+    float* lvec = reinterpret_cast<float*>(smem48 + G::l_vec16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ws = blockIdx.y, r = lane & 31, hf = lane >> 5;
+    const int H = args.H, W = args.W, nwx = W / 16, nwy = H / 16, npi = nwx * nwy;
+    const int nwin = args.B * npi;
+    const int sh = args.shift ? 8 : 0;
+    const int src = args.cross ? 1 - ws : ws;   // the stream whose tokens this stream's attention reads as keys / values
+
+    for (int i = tid; i < 2 * G::VSTREAM; i += 256)
+        lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(args.packed[ws]), 0, (int)G::p_total16, 0x00020000);
+    const int act_bytes = args.B * H * W * 48 * 4;   // < 2^31 (launch_win48)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.in[ws]), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.in[src]), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(args.out[ws], 0, act_bytes, 0x00020000);
+    const unsigned loff = (unsigned)lane * 16u;
+    auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };
+    const float* vec = lvec + ws * G::VSTREAM + hf * G::VHF;        // own stream, own lane half (also the K bias: own weights)
+    const float* vecs = lvec + src * G::VSTREAM + hf * G::VHF;      // LN1 parameters of the key / value tokens' stream
+    const float* vecv = lvec + ws * G::VSTREAM + 2 * G::VHF;        // V bias [tile][32]
+    const bool half1 = hf != 0;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        SWF_WF_FENCE();
+        const int b = win / npi, wrem = win - b * npi;
+        const int wy = wrem / nwx, wx = wrem - wy * nwx;
+        auto tokoff_of = [&](int j) {   // tile j = window rows 2j, 2j+1; the lane's token: row 2j + (r >> 4), column r & 15
+            int oy = wy * 16 + 2 * j + (r >> 4) + sh, ox = wx * 16 + (r & 15) + sh;
+            oy = oy >= H ? oy - H : oy;
+            ox = ox >= W ? ox - W : ox;
+            return (unsigned)((((b * H + oy) * W + ox) * 48 + 4 * hf) * 4);
+        };
+        auto load_rows = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned tokoff, f32x16& t0, f32x16& t1) {
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tokoff, 32 * a, 0));
+                if (a < 4) { t0[4 * a] = v.x; t0[4 * a + 1] = v.y; t0[4 * a + 2] = v.z; t0[4 * a + 3] = v.w; }
+                else { t1[4 * (a - 4)] = v.x; t1[4 * (a - 4) + 1] = v.y; t1[4 * (a - 4) + 2] = v.z; t1[4 * (a - 4) + 3] = v.w; }
+            }
+#pragma unroll
+            for (int i = 8; i < 16; ++i) t1[i] = 0.f;
+        };
+
+        // ---- phase A: LN1 of the wave's two tiles (own tokens for Q, the key / value stream's for K and V), six tile phases ----
+        u32x4 qf[2][2][2];   // [tile of the wave][vch tile][k-step]
+        {
+            u32x4 xh[2][3], xl[2][3], kh[2][3], kl[2][3];
+#pragma unroll
+            for (int jj = 0; jj < 2; ++jj) {
+                const unsigned tokoff = tokoff_of(2 * wave + jj);
+                f32x16 x0, x1;
+                load_rows(irs, tokoff, x0, x1);
+                layernorm48(x0, x1, vec, G::V_LN1G, G::V_LN1B, xh[jj], xl[jj]);
+                if (args.cross) {
+                    load_rows(srs, tokoff, x0, x1);
+                    layernorm48(x0, x1, vecs, G::V_LN1G, G::V_LN1B, kh[jj], kl[jj]);
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) { kh[jj][s2] = xh[jj][s2]; kl[jj][s2] = xl[jj][s2]; }
+                }
+            }
+            u32x4 wq[2][6];
+            auto req = [&](int ph, u32x4 (&dst)[6]) {
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dst[i] = WF(G::F_QKV + ph * 6 + i);   // [q,k,v][tile][k-step][hi,lo]
+            };
+            req(0, wq[0]);
+#pragma unroll
+            for (int ph = 0; ph < 6; ++ph) {
+                const int m = ph >> 1, T = ph & 1;
+                SWF_WF_FENCE();
+                if (ph + 1 < 6) req(ph + 1, wq[(ph + 1) & 1]);
+                SWF_WF_FENCE();
+                const u32x4 (&w)[6] = wq[ph & 1];
+#pragma unroll
+                for (int jj = 0; jj < 2; ++jj) {
+                    const int j = 2 * wave + jj;
+                    f32x16 acc = zero16;
+                    float t[16];
+                    if (m < 2) {
+#pragma unroll
+                        for (int s2 = 0; s2 < 3; ++s2)
+                            acc = m == 0 ? mma3(w[2 * s2], w[2 * s2 + 1], xh[jj][s2], xl[jj][s2], acc) : mma3(w[2 * s2], w[2 * s2 + 1], kh[jj][s2], kl[jj][s2], acc);
+                        const float* bsrc = m == 0 ? vec + G::V_BQ : vec + G::V_BK;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bb = *reinterpret_cast<const float4*>(bsrc + 16 * T + 4 * g);
+                            t[4 * g] = acc[4 * g] + bb.x; t[4 * g + 1] = acc[4 * g + 1] + bb.y; t[4 * g + 2] = acc[4 * g + 2] + bb.z; t[4 * g + 3] = acc[4 * g + 3] + bb.w;
+                        }
+                        if (m == 0) {
+                            qf[jj][T][0] = pack8_f16(t);
+                            qf[jj][T][1] = pack8_f16(t + 8);
+                        } else {
+                            u32x4* kdst = kimg + ((j * 2 + T) * 2) * 64 + lane;
+                            kdst[0] = pack8_f16(t);
+                            kdst[64] = pack8_f16(t + 8);
+                        }
+                    } else {   // V: tokens in rows (A = x fragments, B = weight fragments)
+#pragma unroll
+                        for (int s2 = 0; s2 < 3; ++s2) acc = mma3(kh[jj][s2], kl[jj][s2], w[2 * s2], w[2 * s2 + 1], acc);
+                        const float bv = vecv[32 * T + r];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) t[i] = acc[i] + bv;
+                        u32x4* vdst = vimg + (T * 16 + 2 * j) * 64 + lane;
+                        vdst[0] = pack8_f16(t);
+                        vdst[64] = pack8_f16(t + 8);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // K / V^T images of all 256 keys complete
+
+        // ---- phase B ----
+        const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
+#pragma unroll 1
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * wave + jj;   // query tile
+            const unsigned tokoff = tokoff_of(j);
+            f32x16 o[2] = {zero16, zero16};
+            float mrun[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) mrun[h] = -INFINITY;
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                if (rowv && ((j < 4) != (c < 2))) continue;   // keys across the row seam: probabilities exactly 0
+                f32x16 bias[2];
+                {
+                    const int d0 = __builtin_amdgcn_readfirstlane(2 * c - j + 7);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((d0 + kt) * 4 + a) * 1024, 0));
+                            bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
+                        }
+                    if (colv) {
+                        const bool qhi = (r & 8) != 0;
+                        const float pen_lo = qhi ? -INFINITY : 0.f, pen_hi = qhi ? 0.f : -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float pen = ((i >> 2) & 1) ? pen_hi : pen_lo;
+                            bias[0][i] += pen; bias[1][i] += pen;
+                        }
+                    }
+                }
+                const u32x4* kc = kimg + (2 * c) * 4 * 64 + lane;   // key tiles 2c, 2c + 1: 4 fragments each
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int T = h >> 2, hq = h & 3, sp = hq >> 1, sub = hq & 1;
+                    const u32x4 ka0 = kc[((0 * 2 + T) * 2 + sp) * 64], ka1 = kc[((1 * 2 + T) * 2 + sp) * 64];
+                    u32x4 qm = {0u, 0u, 0u, 0u};
+                    qm[2 * sub] = qf[0][T][sp][2 * sub];
+                    qm[2 * sub + 1] = qf[0][T][sp][2 * sub + 1];
+                    float mx;
+                    {
+                        f32x16 s0 = mfma_f16(ka0, qm, bias[0]);
+                        mx = max3f(s0[0], s0[1], s0[2]);
+#pragma unroll
+                        for (int i = 3; i < 15; i += 2) mx = max3f(mx, s0[i], s0[i + 1]);
+                        mx = __builtin_fmaxf(mx, s0[15]);
+                    }
+                    {
+                        f32x16 s1 = mfma_f16(ka1, qm, bias[1]);
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+                    }
+                    mx = max_halves(mx);
+                    const float mold = mrun[h];
+                    const f16 nm = (f16)(-__builtin_fmaxf(mold, mx));
+                    const float mnew = -(float)nm;   // the shift the second pass really applies
+                    const float alpha = __builtin_amdgcn_exp2f(mold - mnew);
+                    mrun[h] = mnew;
+                    qm[2 * sub + 1] |= half1 ? ((unsigned)__builtin_bit_cast(unsigned short, nm) << 16) : 0u;
+                    f32x16 t;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        f32x16 sc = mfma_f16(kt ? ka1 : ka0, qm, bias[kt]);
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            float pe[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) pe[e] = __builtin_amdgcn_exp2f(sc[8 * s2 + e]);
+                            const u32x4 pf = pack8_f16(pe);
+                            const u32x4 va = vimg[(T * 16 + 4 * c + 2 * kt + s2) * 64 + lane];
+                            t = mfma_f16(va, pf, (kt == 0 && s2 == 0) ? zero16 : t);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) o[T][4 * hq + e] = __builtin_fmaf(o[T][4 * hq + e], alpha, t[4 * hq + e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the second tile's Q fragments move up
+#pragma unroll
+            for (int T = 0; T < 2; ++T) { qf[0][T][0] = qf[1][T][0]; qf[0][T][1] = qf[1][T][1]; }
+
+            // ---- normalise, output projection + bias + residual ----
+            f32x16 res0, res1;
+            SWF_WF_FENCE();
+            load_rows(irs, tokoff, res0, res1);
+            {
+                u32x4 oh[4], ol[4];
+#pragma unroll
+                for (int T = 0; T < 2; ++T) {
+                    float t[16];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float lo_, den;
+                        halves(o[T][4 * q + 2], lo_, den);
+                        const float inv = __builtin_amdgcn_rcpf(den);
+                        t[4 * q] = o[T][4 * q] * inv; t[4 * q + 1] = o[T][4 * q + 1] * inv; t[4 * q + 2] = o[T][4 * q + 2] * inv; t[4 * q + 3] = o[T][4 * q + 3] * inv;
+                    }
+                    split8(t, oh[2 * T], ol[2 * T]);
+                    split8(t + 8, oh[2 * T + 1], ol[2 * T + 1]);
+                }
+                SWF_WF_FENCE();
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    res0 = mma3(WF(G::F_P + (0 * 4 + ks) * 2), WF(G::F_P + (0 * 4 + ks) * 2 + 1), oh[ks], ol[ks], res0);
+                    res1 = mma3(WF(G::F_P + (1 * 4 + ks) * 2), WF(G::F_P + (1 * 4 + ks) * 2 + 1), oh[ks], ol[ks], res1);
+                }
+            }
+            // ---- LN2, MLP ----
+            {
+                u32x4 w1[2][6];
+                auto req1 = [&](int tI, u32x4 (&dst)[6]) {
+#pragma unroll
+                    for (int i = 0; i < 6; ++i) dst[i] = WF(G::F_W1 + tI * 6 + i);
+                };
+                req1(0, w1[0]);
+                u32x4 xh[3], xl[3];
+                layernorm48(res0, res1, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+#pragma unroll
+                for (int tI = 0; tI < G::NT1; ++tI) {
+                    SWF_WF_FENCE();
+                    u32x4 w2[2][2][2];
+#pragma unroll
+                    for (int To = 0; To < 2; ++To)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            w2[To][s2][0] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2);
+                            w2[To][s2][1] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2 + 1);
+                        }
+                    if (tI + 1 < G::NT1) req1(tI + 1, w1[(tI + 1) & 1]);
+                    SWF_WF_FENCE();
+                    const u32x4 (&w)[6] = w1[tI & 1];
+                    f32x16 acc = zero16;
+#pragma unroll
+                    for (int s2 = 0; s2 < 3; ++s2) acc = mma3(w[2 * s2], w[2 * s2 + 1], xh[s2], xl[s2], acc);
+                    float e[16];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b1 = *reinterpret_cast<const float4*>(vec + G::V_B1 + 16 * tI + 4 * g);
+                        const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) {
+                            const float u = acc[4 * g + jx] + bb[jx];
+                            const float L = __builtin_fmaf(__builtin_amdgcn_exp2f(u), kLog2e, -kLog2e);
+                            e[4 * g + jx] = __builtin_amdgcn_fmed3f(u, L, 0.f);
+                        }
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u32x4 hh, hl;
+                        split8(e + 8 * s2, hh, hl);
+                        res0 = mma3(w2[0][s2][0], w2[0][s2][1], hh, hl, res0);
+                        res1 = mma3(w2[1][s2][0], w2[1][s2][1], hh, hl, res1);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+#pragma unroll
+                for (int a = 0; a < 6; ++a) {
+                    const float4 b2 = *reinterpret_cast<const float4*>(vec + G::V_B2 + 4 * a);
+                    if (a < 4) { res0[4 * a] += b2.x; res0[4 * a + 1] += b2.y; res0[4 * a + 2] += b2.z; res0[4 * a + 3] += b2.w; }
+                    else { res1[4 * (a - 4)] += b2.x; res1[4 * (a - 4) + 1] += b2.y; res1[4 * (a - 4) + 2] += b2.z; res1[4 * (a - 4) + 3] += b2.w; }
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 6; ++a) {
+                const f32x4 v = a < 4 ? f32x4{res0[4 * a], res0[4 * a + 1], res0[4 * a + 2], res0[4 * a + 3]}
+                                      : f32x4{res1[4 * (a - 4)], res1[4 * (a - 4) + 1], res1[4 * (a - 4) + 2], res1[4 * (a - 4) + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, tokoff, 32 * a, 0);
+            }
+        }
+        __syncthreads();   // every wave is done with the images: the next window may overwrite them
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct Pack48Args {
     swf_block_stream_params p[2];
     char* dst[2];
@@ -478,6 +789,15 @@ __global__ __launch_bounds__(256) void pack48_kernel(Pack48Args a) {
     }
     // relative-position bias (a001:113-144), exp2 units: [query block][key tile][register / 4][lane][register % 4]
     float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    if (a.ws == 16) {   // [distance kt - qb + 7][register / 4][lane][register % 4]; a tile = two window rows of 16
+        for (int i = gtid; i < 15 * 16 * 64; i += gsz) {
+            const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, d = i >> 10;
+            const int key = rho(4 * a4 + j, lane >> 5), q = lane & 31;
+            const int dy = 2 * (d - 7) + (key >> 4) - (q >> 4), dx = (key & 15) - (q & 15);
+            bm[i] = p.attn.bias_table[(dy + 15) * 31 + (dx + 15)] * kLog2e;
+        }
+        return;
+    }
     for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
         const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, kt = (i >> 10) & 1, qb = i >> 11;
         const int key = 32 * kt + rho(4 * a4 + j, lane >> 5), q = 32 * qb + (lane & 31);
@@ -501,12 +821,13 @@ int num_cus48() {
 }  // namespace
 
 bool win48_supported(const swf_block_desc& d) {
-    return d.attn.channels == 48 && d.attn.heads == 8 && d.attn.head_dim == 6 && d.attn.win_h == d.attn.win_w && (d.attn.win_h == 8 || d.attn.win_h == 7) &&
+    return d.attn.channels == 48 && d.attn.heads == 8 && d.attn.head_dim == 6 && d.attn.win_h == d.attn.win_w && (d.attn.win_h == 8 || d.attn.win_h == 7 || d.attn.win_h == 16) &&
            (d.hidden == 192 || d.hidden == 96);
 }
 
 size_t win48_packed_bytes(const swf_block_desc& d) {
     if (!win48_supported(d)) return 0;
+    if (d.attn.win_h == 16) return align_up(d.hidden == 192 ? G48<192>::p_total16 : G48<96>::p_total16, 256);
     return align_up(d.hidden == 192 ? G48<192>::p_total : G48<96>::p_total, 256);
 }
 
@@ -536,6 +857,17 @@ int launch_win48(const swf_block_desc& d, const void* packed_x, const void* pack
     a.warm_bytes = (int)(next_bytes ? next_bytes : win48_packed_bytes(d));
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
     const int nwin = B * (H / wsd) * (W / wsd);
+    if (wsd == 16) {   // 69 KB of LDS per workgroup (dynamic), two workgroups per CU, grid.y = stream
+        static hipError_t attr_err = [] {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window48w16_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G48<192>::l_total16);
+            return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(&window48w16_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G48<96>::l_total16);
+        }();
+        if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window48w16): %s", hipGetErrorString(attr_err));
+        const int gx = std::min(nwin, num_cus48());
+        if (d.hidden == 192) hipLaunchKernelGGL((window48w16_kernel<192>), dim3(gx, 2), dim3(256), G48<192>::l_total16, stream, a);
+        else hipLaunchKernelGGL((window48w16_kernel<96>), dim3(gx, 2), dim3(256), G48<96>::l_total16, stream, a);
+        return check_launch("window48w16");
+    }
     const int grid = std::min(nwin, W48_WAVES * num_cus48());
     if (wsd == 8) {
         if (d.hidden == 192) hipLaunchKernelGGL((window48_kernel<192, 8>), dim3(grid), dim3(256), 0, stream, a);

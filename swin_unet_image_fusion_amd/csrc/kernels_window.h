@@ -10,6 +10,8 @@ bool window_block_supported(const swf_block_desc& d, int B, int H, int W);
 size_t window_block_packed_bytes(const swf_block_desc& d);
 // workspace needed by the block-level entry (packs both streams per call)
 size_t window_block_workspace_bytes(const swf_block_desc& d, int B, int H, int W);
+// true: launch_window_block needs x_out / y_out distinct from x_in / y_in (the caller routes in-place calls through a temporary)
+bool window_block_out_of_place(const swf_block_desc& d);
 
 // fp32 parameters -> kernel layout (split-bf16 hi/lo weight images, pre-scaled Wq, the four
 // masked/unmasked relative-position bias matrices).  One launch for both streams.

@@ -1398,8 +1398,16 @@ size_t window_block_packed_bytes(const swf_block_desc& d) {
     return 0;
 }
 
+// The 16x16-window kernel at C = 48 runs one workgroup per (window, stream): in a cross block the workgroup of one stream reads the
+// other stream's tokens while that stream's workgroup writes its results, so the outputs must not alias the inputs.
+bool window_block_out_of_place(const swf_block_desc& d) {
+    return use_win48(d) && d.attn.win_h == 16;
+}
+
 size_t window_block_workspace_bytes(const swf_block_desc& d, int B, int H, int W) {
-    return window_block_supported(d, B, H, W) ? 2 * window_block_packed_bytes(d) : 0;
+    if (!window_block_supported(d, B, H, W)) return 0;
+    // packed weights of both streams (callers without a pre-packed image) + two temporary output maps for in-place callers
+    return 2 * window_block_packed_bytes(d) + (window_block_out_of_place(d) ? (size_t)2 * B * H * W * d.attn.channels * 4 + 512 : 0);
 }
 
 int pack_window_block(const swf_block_desc& d, const swf_block_stream_params& px, const swf_block_stream_params& py,

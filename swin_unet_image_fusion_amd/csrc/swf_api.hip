@@ -392,14 +392,34 @@ static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_p
                             const swf_block_stream_params* const* next_p = nullptr, bool* ln1_ready = nullptr) {
     // next_p / ln1_ready: see deep_block_impl; every other path ignores the planes and leaves *ln1_ready false
     if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W)) {
-        if (prepacked_x && prepacked_y)   // model path: weights were packed once (swf_model_pack_weights)
-            return launch_window_block(*desc, prepacked_x, prepacked_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_x, next_y, next_bytes);
-        // block-level entry: pack this block's weights into the workspace, then one fused launch
+        const bool prepacked = prepacked_x && prepacked_y;   // model path: weights were packed once (swf_model_pack_weights)
         const size_t pb = window_block_packed_bytes(*desc);
-        if (!workspace || workspace_bytes < 2 * pb) return fail(SWF_ERR_WORKSPACE, "fused block workspace too small (need %zu B)", 2 * pb);
         char* w = static_cast<char*>(workspace);
-        SWF_TRY(pack_window_block(*desc, *px, *py, w, w + pb, stream));
-        return launch_window_block(*desc, w, w + pb, x_in, y_in, x_out, y_out, B, H, W, stream);
+        size_t used = prepacked ? 0 : 2 * pb;
+        if (!prepacked && (!workspace || workspace_bytes < used)) return fail(SWF_ERR_WORKSPACE, "fused block workspace too small (need %zu B)", used);
+        // a kernel whose workgroups read one stream while others write it (kernels_window.h) gets temporary outputs when called in place
+        float *ox = x_out, *oy = y_out;
+        const size_t map_bytes = (size_t)B * H * W * desc->attn.channels * 4;
+        const bool via_tmp = window_block_out_of_place(*desc) && desc->cross && (x_in == x_out || y_in == y_out || x_in == y_out || y_in == x_out);
+        if (via_tmp) {
+            used = align_up(used, 256);
+            if (!workspace || workspace_bytes < used + 2 * map_bytes)
+                return fail(SWF_ERR_WORKSPACE, "fused block workspace too small (need %zu B)", used + 2 * map_bytes);
+            ox = reinterpret_cast<float*>(w + used);
+            oy = reinterpret_cast<float*>(w + used + map_bytes);
+        }
+        if (prepacked) {
+            SWF_TRY(launch_window_block(*desc, prepacked_x, prepacked_y, x_in, y_in, ox, oy, B, H, W, stream, next_x, next_y, next_bytes));
+        } else {   // block-level entry: pack this block's weights into the workspace, then one fused launch
+            SWF_TRY(pack_window_block(*desc, *px, *py, w, w + pb, stream));
+            SWF_TRY(launch_window_block(*desc, w, w + pb, x_in, y_in, ox, oy, B, H, W, stream));
+        }
+        if (via_tmp) {
+            if (hipMemcpyAsync(x_out, ox, map_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess ||
+                hipMemcpyAsync(y_out, oy, map_bytes, hipMemcpyDeviceToDevice, stream) != hipSuccess)
+                return fail(SWF_ERR_HIP, "fused block: copy of the temporary outputs failed");
+        }
+        return SWF_OK;
     }
     auto aligned16 = [](const swf_block_stream_params* p) {
         if (!p) return true;
