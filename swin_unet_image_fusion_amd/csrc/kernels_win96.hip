@@ -1,0 +1,534 @@
+// Level-2 fused BasicBlock (a005:127-145) at C = 96 (8 heads of 12, 8x8 or 7x7 windows, hidden 384 / 192): the register-resident
+// design of kernels_win24.hip / kernels_win48.hip one size up.  A 256-thread workgroup walks windows; wave (stream w >> 1, 32-token
+// half w & 1) owns its tokens through every phase, the MFMA accumulator layout of one linear is the operand layout of the next
+// (weights packed with their k columns in accumulator order), and only the K / V^T images of the attention cross waves (64 KB
+// of LDS for both streams, two workgroups per CU).
+//
+// Layouts.  Channels: three 32-channel tiles; register i of tile T in lane (token r, half hf) is channel 32T + rho(i, hf).
+// Attention: a head owns 16 virtual channels (12 real + 4 spare) = ONE 16-deep k-step: virtual-channel tile T holds heads 2T and
+// 2T + 1 as its k-steps 0 and 1, so the Q / K fragments of a head need no masking and S^T of a head is one MFMA per key tile.
+// Within a head's k-step lane half 0 holds channels 0-3 and 8-11, lane half 1 channels 4-7 and the spare rows 12-15: row 12 is
+// the constant 1 in V (softmax denominator), row 13 the constant 1 in K against -max in Q (S - max on the matrix pipe).
+#include "kernels_win96.h"
+
+#include <algorithm>
+
+#include "win_frag.h"
+
+namespace swf {
+namespace {
+
+using namespace wf;
+
+template <int HID_>
+struct G96 {
+    static constexpr int C = 96, HID = HID_, HEADS = 8, D = 12, TC = 3, VT = 4, KS = 6;
+    static constexpr int NT1 = HID / 32, KU = HID / 16;
+    static_assert(HID % 32 == 0, "hidden tiles");
+    static constexpr int F_QKV = 0;                    // [q,k,v][vch tile 4][k-step 6][hi,lo]
+    static constexpr int F_P = 144;                    // [out tile 3][k-step 8][hi,lo]
+    static constexpr int F_W1 = 192;                   // [tile NT1][k-step 6][hi,lo]
+    static constexpr int F_W2 = F_W1 + 12 * NT1;       // [out tile 3][k-step KU][hi,lo]
+    static constexpr int NFRAG = F_W2 + 6 * KU;
+    // fp32 vectors per lane half: [LN1G 48 | LN1B 48 | LN2G 48 | LN2B 48 | B2 48 | BQ 64 | BK 64 | B1 16*NT1]; then BV [4 tiles][32]
+    static constexpr int V_LN1G = 0, V_LN1B = 48, V_LN2G = 96, V_LN2B = 144, V_B2 = 192, V_BQ = 240, V_BK = 304, V_B1 = 368;
+    static constexpr int VHF = V_B1 + 16 * NT1, VSTREAM = 2 * VHF + 128;
+    static constexpr size_t p_vec = size_t(NFRAG) * 1024;
+    static constexpr size_t p_bias = (p_vec + size_t(VSTREAM) * 4 + 15) / 16 * 16;   // fp32 [query block 2][key tile 2][reg/4 4][lane 64][4]
+    static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
+    // LDS: K images [stream 2][key tile 2][vch tile 4][k-step 2] x 1 KB, V^T images [stream 2][vch tile 4][pv-step 4] x 1 KB, vectors
+    static constexpr size_t l_k = 0, l_v = 32 * 1024, l_vec = 64 * 1024, l_total = l_vec + size_t(2) * VSTREAM * 4;
+};
+
+struct Win96Args {
+    const float* in[2];
+    float* out[2];
+    const char* packed[2];
+    const char* warm[2];
+    int B, H, W, shift, cross, warm_bytes;
+};
+
+// LayerNorm (eps 1e-5, biased variance) of the lane's token: 48 of its 96 channels sit in this lane (three tiles x 16 registers),
+// the other 48 in lane l ^ 32.  Output: the six k-step fragments of the next linear layer.
+__device__ __forceinline__ void layernorm96(const f32x16 (&x)[3], const float* vec, int goff, int boff, u32x4 (&xh)[6], u32x4 (&xl)[6]) {
+    float s = 0.f;
+#pragma unroll
+    for (int T = 0; T < 3; ++T)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) s += x[T][i];
+    const float mean = sum_halves(s) * (1.0f / 96.0f);
+    float q = 0.f;
+#pragma unroll
+    for (int T = 0; T < 3; ++T)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const float d = x[T][i] - mean;
+            q += d * d;
+        }
+    const float rstd = __builtin_amdgcn_rsqf(sum_halves(q) * (1.0f / 96.0f) + 1e-5f);
+#pragma unroll
+    for (int T = 0; T < 3; ++T) {
+        float n[16];
+#pragma unroll
+        for (int a = 0; a < 4; ++a) {
+            const float4 g = *reinterpret_cast<const float4*>(vec + goff + 16 * T + 4 * a);
+            const float4 b = *reinterpret_cast<const float4*>(vec + boff + 16 * T + 4 * a);
+            n[4 * a + 0] = (x[T][4 * a + 0] - mean) * rstd * g.x + b.x;
+            n[4 * a + 1] = (x[T][4 * a + 1] - mean) * rstd * g.y + b.y;
+            n[4 * a + 2] = (x[T][4 * a + 2] - mean) * rstd * g.z + b.z;
+            n[4 * a + 3] = (x[T][4 * a + 3] - mean) * rstd * g.w + b.w;
+        }
+        split8(n, xh[2 * T], xl[2 * T]);
+        split8(n + 8, xh[2 * T + 1], xl[2 * T + 1]);
+    }
+}
+
+// Attention of one wave: 32 queries x 64 keys x 8 heads.  ksrc / vsrc: the stream's K and V^T images in LDS (+ lane); qf[tile][k-step]:
+// the wave's Q fragments (k-step = head within the tile); bias: relative-position bias of (stream, query block) with -inf where the
+// shift mask applies.  Returns the four O^T tiles: registers 8*sp .. 8*sp + 7 of tile T = head 2T + sp (lane half 1: register
+// 8*sp + 4 is the softmax denominator).
+__device__ __forceinline__ void attention96(const u32x4* ksrc, const u32x4* vsrc, const u32x4 (&qf)[4][2], const f32x16 (&bias)[2],
+                                            bool half1, f32x16 (&o)[4]) {
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int T = 0; T < 4; ++T) o[T] = zero16;
+#pragma unroll
+    for (int h = 0; h < 8; ++h) {
+        const int T = h >> 1, sp = h & 1;
+        const u32x4 ka0 = ksrc[((0 * 4 + T) * 2 + sp) * 64], ka1 = ksrc[((1 * 4 + T) * 2 + sp) * 64];
+        u32x4 qm = qf[T][sp];
+        float mx;
+        {
+            f32x16 s0 = mfma_f16(ka0, qm, bias[0]);   // S^T[key][query] + bias, exp2 units
+            mx = max3f(s0[0], s0[1], s0[2]);
+#pragma unroll
+            for (int i = 3; i < 15; i += 2) mx = max3f(mx, s0[i], s0[i + 1]);
+            mx = __builtin_fmaxf(mx, s0[15]);
+        }
+        {
+            f32x16 s1 = mfma_f16(ka1, qm, bias[1]);
+#pragma unroll
+            for (int i = 0; i < 16; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+        }
+        mx = max_halves(mx);
+        // S - max on the matrix pipe: the head's row 13 (lane half 1, element 5 = upper half of dword 2) is 1 in K and -max (f16) in Q
+        {
+            const f16 nm = (f16)(-mx);
+            qm[2] |= half1 ? ((unsigned)__builtin_bit_cast(unsigned short, nm) << 16) : 0u;
+        }
+        f32x16 t;
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt) {
+            f32x16 sc = mfma_f16(kt ? ka1 : ka0, qm, bias[kt]);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2) {
+                float p[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) p[j] = __builtin_amdgcn_exp2f(sc[8 * s2 + j]);
+                const u32x4 pf = pack8_f16(p);
+                const u32x4 va = vsrc[(T * 4 + 2 * kt + s2) * 64];
+                t = mfma_f16(va, pf, (kt == 0 && s2 == 0) ? zero16 : t);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[T][8 * sp + j] = t[8 * sp + j];
+        __builtin_amdgcn_sched_barrier(0);   // one head at a time
+    }
+}
+
+// WS = window side, 8 or 7 (the reference's default): 7x7 windows run on the 8x8 token grid, padding tokens beyond the buffer
+// range (reads 0, stores dropped) and -inf in the packed bias matrix as keys (kernels_win24.hip).
+template <int HID, int WS>
+__global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
+    using G = G96<HID>;
+    static_assert(WS == 7 || WS == 8, "window side");
+    extern __shared__ __attribute__((aligned(16))) char smem96[];
+    u32x4* kimg = reinterpret_cast<u32x4*>(smem96 + G::l_k);   // [stream][key tile][vch tile][k-step][lane]
+    u32x4* vimg = reinterpret_cast<u32x4*>(smem96 + G::l_v);   // [stream][vch tile][pv-step][lane]
+    float* lvec = reinterpret_cast<float*>(smem96 + G::l_vec);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ws = wave >> 1, qb = wave & 1, r = lane & 31, hf = lane >> 5;
+    const int H = args.H, W = args.W, nwx = W / WS, nwy = H / WS, npi = nwx * nwy;
+    const int nwin = args.B * npi;
+    const int sh = args.shift ? WS / 2 : 0;
+    const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
+
+    for (int i = tid; i < 2 * G::VSTREAM; i += 256)
+        lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
+    const int act_bytes = args.B * H * W * 96 * 4;   // < 2^31 (launch_win96)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(args.in[ws])), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, act_bytes, 0x00020000);
+    const unsigned loff = (unsigned)lane * 16u;
+    auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };   // own stream: Q, proj, MLP
+    auto WK = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, loff, f * 1024, 0)); };   // K / V weights
+    const float* vec = lvec + ws * G::VSTREAM + hf * G::VHF;       // own stream, own lane half
+    const float* veck = lvec + kvs * G::VSTREAM + hf * G::VHF;     // K bias: the stream whose weights produce K
+    const float* vecv = lvec + kvs * G::VSTREAM + 2 * G::VHF;      // V bias [tile][32]
+    const bool half1 = hf != 0;
+    const bool col_masked = half1 != (((r >> 2) & 1) != 0);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        SWF_WF_FENCE();
+        const int b = win / npi, wrem = win - b * npi;
+        const int wy = wrem / nwx, wx = wrem - wy * nwx;
+        const int ty = 4 * qb + (r >> 3), tx = r & 7;
+        int oy = wy * WS + ty + sh, ox = wx * WS + tx + sh;
+        oy = oy >= H ? oy - H : oy;
+        ox = ox >= W ? ox - W : ox;
+        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 96 + 4 * hf) * 4) : 0x80000000u;
+        // the lane's 48 channels: float4 a (0..11) = channels 8a + 4hf .. +3 = registers 4(a & 3) .. of tile a >> 2
+        auto load_rows = [&](f32x16 (&x)[3]) {
+#pragma unroll
+            for (int a = 0; a < 12; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, tokoff, 32 * a, 0));
+                x[a >> 2][4 * (a & 3)] = v.x; x[a >> 2][4 * (a & 3) + 1] = v.y; x[a >> 2][4 * (a & 3) + 2] = v.z; x[a >> 2][4 * (a & 3) + 3] = v.w;
+            }
+        };
+
+        // ---- LN1, then Q (own stream's weights), K and V (weights of the stream that attends to these tokens) ----
+        u32x4 qf[4][2];
+        {
+            // 24 half phases: (Q, K, V) x 4 virtual-channel tiles x two halves of the six k-steps, 6 weight fragments each; the
+            // fragments of half phase p + 1 are requested before the MFMAs of half phase p (double register set, fences pin the
+            // issue points; vmcnt retires in order, so p's data is waited for while p + 1's stays in flight)
+            u32x4 wq[2][6];
+            auto req = [&](int hp, u32x4 (&dst)[6]) {
+                const int m = hp >> 3, f0 = G::F_QKV + ((hp >> 1) * 6 + 3 * (hp & 1)) * 2;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dst[i] = m == 0 ? WF(f0 + i) : WK(f0 + i);
+            };
+            req(0, wq[0]);
+            u32x4 xh[6], xl[6];
+            {
+                f32x16 x[3];
+                load_rows(x);
+                layernorm96(x, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+            }
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int hp = 0; hp < 24; ++hp) {
+                const int m = hp >> 3, T = (hp >> 1) & 3, half = hp & 1;
+                SWF_WF_FENCE();
+                if (hp + 1 < 24) req(hp + 1, wq[(hp + 1) & 1]);
+                SWF_WF_FENCE();
+                const u32x4 (&w)[6] = wq[hp & 1];
+                if (half == 0) acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int ks = 3 * half + s;
+                    acc = m < 2 ? mma3(w[2 * s], w[2 * s + 1], xh[ks], xl[ks], acc)      // [virtual channel][token]
+                                : mma3(xh[ks], xl[ks], w[2 * s], w[2 * s + 1], acc);     // V: [token][virtual channel]
+                }
+                if (half == 1) {
+                    float t[16];
+                    if (m < 2) {
+                        const float* bsrc = m == 0 ? vec + G::V_BQ : veck + G::V_BK;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bb = *reinterpret_cast<const float4*>(bsrc + 16 * T + 4 * g);
+                            t[4 * g] = acc[4 * g] + bb.x; t[4 * g + 1] = acc[4 * g + 1] + bb.y; t[4 * g + 2] = acc[4 * g + 2] + bb.z; t[4 * g + 3] = acc[4 * g + 3] + bb.w;
+                        }
+                        if (m == 0) {
+                            qf[T][0] = pack8_f16(t);
+                            qf[T][1] = pack8_f16(t + 8);
+                        } else {
+                            if (T == 0 && win != (int)blockIdx.x) __syncthreads();   // the attention phase of the window before has read the images
+                            u32x4* kdst = kimg + (((kvs * 2 + qb) * 4 + T) * 2) * 64 + lane;
+                            kdst[0] = pack8_f16(t);
+                            kdst[64] = pack8_f16(t + 8);
+                        }
+                    } else {
+                        const float bv = vecv[32 * T + r];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) t[i] = acc[i] + bv;
+                        u32x4* vdst = vimg + ((kvs * 4 + T) * 4 + 2 * qb) * 64 + lane;
+                        vdst[0] = pack8_f16(t);
+                        vdst[64] = pack8_f16(t + 8);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // K / V^T images of both streams complete
+
+        // ---- attention of the wave's 32 queries, 8 heads (shift mask: kernels_win24.hip) ----
+        f32x16 o[4];
+        {
+            f32x16 bias[2];
+#pragma unroll
+            for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                for (int a = 0; a < 4; ++a) {
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((qb * 2 + kt) * 4 + a) * 1024, 0));
+                    bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
+                }
+            const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
+            const u32x4* ksrc = kimg + (ws * 16) * 64 + lane;
+            const u32x4* vsrc = vimg + (ws * 16) * 64 + lane;
+            if (rowv || colv) {   // wave-uniform: the mask is a whole key tile / a whole lane, folded into the C operand once per window
+                const float pen0 = ((rowv && qb == 1) || (colv && col_masked)) ? -INFINITY : 0.f;
+                const float pen1 = ((rowv && qb == 0) || (colv && col_masked)) ? -INFINITY : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { bias[0][i] += pen0; bias[1][i] += pen1; }
+            }
+            attention96(ksrc, vsrc, qf, bias, half1, o);
+        }
+
+        // ---- normalise (denominator: lane half 1, register 8sp + 4 of the head's tile), output projection + bias + residual ----
+        f32x16 res[3];
+        SWF_WF_FENCE();
+        load_rows(res);
+        {
+            u32x4 oh[8], ol[8];   // k-step = head
+#pragma unroll
+            for (int h = 0; h < 8; ++h) {
+                const int T = h >> 1, sp = h & 1;
+                float lo_, den;
+                halves(o[T][8 * sp + 4], lo_, den);   // den = the value of lanes 32..63
+                const float inv = __builtin_amdgcn_rcpf(den);
+                float t[8];
+                // lane half 1: element 4 becomes den / den = 1 (the projection bias rides on head 0's), elements 5..7 stay 0
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = o[T][8 * sp + j] * inv;
+                split8(t, oh[h], ol[h]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 8; ++ks) {
+                SWF_WF_FENCE();
+                u32x4 wp[3][2];
+#pragma unroll
+                for (int To = 0; To < 3; ++To) { wp[To][0] = WF(G::F_P + (To * 8 + ks) * 2); wp[To][1] = WF(G::F_P + (To * 8 + ks) * 2 + 1); }
+#pragma unroll
+                for (int To = 0; To < 3; ++To) res[To] = mma3(wp[To][0], wp[To][1], oh[ks], ol[ks], res[To]);
+            }
+        }
+
+        // ---- LN2, MLP: fc1 tile -> ELU -> split -> two k-steps of fc2 accumulating onto the residual ----
+        {
+            u32x4 xh[6], xl[6];
+            layernorm96(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+            u32x4 w1[12];
+            auto req1 = [&](int tI) {
+#pragma unroll
+                for (int i = 0; i < 12; ++i) w1[i] = WF(G::F_W1 + tI * 12 + i);
+            };
+            req1(0);
+#pragma unroll 1
+            for (int tI = 0; tI < G::NT1; ++tI) {
+                SWF_WF_FENCE();
+                u32x4 w2[3][2][2];   // [out tile][k-step of this hidden tile][hi, lo]: in flight during fc1 and the ELU
+#pragma unroll
+                for (int To = 0; To < 3; ++To)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        w2[To][s2][0] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2);
+                        w2[To][s2][1] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2 + 1);
+                    }
+                SWF_WF_FENCE();
+                f32x16 acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) acc = mma3(w1[2 * s], w1[2 * s + 1], xh[s], xl[s], acc);
+                SWF_WF_FENCE();
+                if (tI + 1 < G::NT1) req1(tI + 1);   // the next tile's fc1 fragments: in flight during the ELU and fc2
+                SWF_WF_FENCE();
+                float e[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b1 = *reinterpret_cast<const float4*>(vec + G::V_B1 + 16 * tI + 4 * g);
+                    const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {   // ELU in exp2 units: median of (u, log2 e (2^u - 1), 0)
+                        const float u = acc[4 * g + j] + bb[j];
+                        const float L = __builtin_fmaf(__builtin_amdgcn_exp2f(u), kLog2e, -kLog2e);
+                        e[4 * g + j] = __builtin_amdgcn_fmed3f(u, L, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 hh, hl;
+                    split8(e + 8 * s2, hh, hl);
+#pragma unroll
+                    for (int To = 0; To < 3; ++To) res[To] = mma3(w2[To][s2][0], w2[To][s2][1], hh, hl, res[To]);
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 12; ++a) {
+                const float4 b2 = *reinterpret_cast<const float4*>(vec + G::V_B2 + 4 * a);
+                res[a >> 2][4 * (a & 3)] += b2.x; res[a >> 2][4 * (a & 3) + 1] += b2.y; res[a >> 2][4 * (a & 3) + 2] += b2.z; res[a >> 2][4 * (a & 3) + 3] += b2.w;
+            }
+        }
+
+        // ---- store the own rows (un-shift = the same index map) ----
+#pragma unroll
+        for (int a = 0; a < 12; ++a) {
+            const f32x4 v = {res[a >> 2][4 * (a & 3)], res[a >> 2][4 * (a & 3) + 1], res[a >> 2][4 * (a & 3) + 2], res[a >> 2][4 * (a & 3) + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, tokoff, 32 * a, 0);
+        }
+    }
+
+    // ---- L2 warm-up of the next block's packed weights (see kernels_window.hip) ----
+    if (args.warm[0]) {
+        const int nsl = max(1, (int)gridDim.x / 8), sl = ((int)blockIdx.x / 8) % nsl;
+        const int lines = (args.warm_bytes + 127) / 128;
+        const int per = (lines + nsl - 1) / nsl, l0 = sl * per, l1 = min(lines, l0 + per);
+        unsigned acc = 0;
+        for (int s2 = 0; s2 < 2; ++s2)
+            for (int l = l0 + tid; l < l1; l += 256) acc ^= *reinterpret_cast<const unsigned*>(args.warm[s2] + (size_t)l * 128);
+        if (acc == 0x9e3779b9u && args.B < 0) args.out[0][0] = 0.f;   // never true: keeps the loads alive
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
+struct Pack96Args {
+    swf_block_stream_params p[2];
+    char* dst[2];
+    int ws;   // window side (7 or 8)
+};
+
+// k index of element e of k-step s in lane half hf, for an operand produced as accumulator tiles: step s covers registers
+// 8(s & 1).. of tile s >> 1
+__host__ __device__ constexpr int kslot(int s, int hf, int e) { return 32 * (s >> 1) + rho(8 * (s & 1) + e, hf); }
+
+template <int HID>
+__global__ __launch_bounds__(256) void pack96_kernel(Pack96Args a) {
+    using G = G96<HID>;
+    const int st = blockIdx.y;
+    const swf_block_stream_params& p = a.p[st];
+    char* dst = a.dst[st];
+    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
+    const float qscale = kLog2e / sqrtf(12.0f);   // d^-0.5 (a001:32-34) and exp -> exp2
+    auto bia = [](const swf_linear& l, int n) { return l.bias ? l.bias[n] : 0.f; };
+
+    for (int idx = gtid; idx < G::NFRAG * 512; idx += gsz) {
+        const int f = idx >> 9, lane = (idx >> 3) & 63, e = idx & 7, r = lane & 31, hf = lane >> 5;
+        const int hl = f & 1;
+        float val = 0.f;
+        if (f < G::F_P) {   // Q / K / V: row (A) or column (B) = virtual channel 32T + r = 16 * head + c; k = input channel in accumulator order
+            const int g = f >> 1, s = g % 6, T = (g / 6) & 3, m = g / 24;
+            const int k = kslot(s, hf, e), vch = 32 * T + r, head = vch >> 4, c = vch & 15;
+            const swf_linear& l = m == 0 ? p.attn.q : m == 1 ? p.attn.k : p.attn.v;
+            if (c < 12) {
+                val = l.weight[(head * 12 + c) * 96 + k];
+                if (m == 0) val *= qscale;
+            }
+        } else if (f < G::F_W1) {   // projection: row = output channel 32To + r; k-step = head, element = the head's row in accumulator order;
+                                    // head 0's row 12 (= 1 after normalisation) carries the bias
+            const int g = (f - G::F_P) >> 1, ks = g & 7, To = g >> 3;
+            const int n = 32 * To + r, row = rho(e, hf);   // rho(8 * 0 + e, hf) of a 16-row head: (e & 3) + 8 (e >> 2) + 4 hf
+            val = row < 12 ? p.attn.proj.weight[n * 96 + ks * 12 + row] : ((ks == 0 && row == 12) ? bia(p.attn.proj, n) : 0.f);
+        } else if (f < G::F_W2) {   // fc1 (exp2 units): row = hidden unit
+            const int g = (f - G::F_W1) >> 1, s = g % 6, tI = g / 6;
+            const int k = kslot(s, hf, e), hid = 32 * tI + r;
+            val = p.fc1.weight[hid * 96 + k] * kLog2e;
+        } else {   // fc2 (x ln 2): row = output channel; k = hidden unit in accumulator order
+            const int g = (f - G::F_W2) >> 1, u = g % G::KU, To = g / G::KU;
+            const int n = 32 * To + r, hid = kslot(u, hf, e);
+            val = p.fc2.weight[n * HID + hid] * kLn2;
+        }
+        const bf16 hi = (bf16)val;
+        reinterpret_cast<bf16*>(dst)[idx] = hl ? (bf16)(val - (float)hi) : hi;
+    }
+    float* vec = reinterpret_cast<float*>(dst + G::p_vec);
+    for (int i = gtid; i < G::VSTREAM; i += gsz) {
+        float v = 0.f;
+        if (i < 2 * G::VHF) {
+            const int hf = i / G::VHF, j = i % G::VHF;
+            if (j < G::V_BQ) {   // 48-entry vectors: entry k = register index (tile k >> 4, register k & 15)
+                const int which = j / 48, k = j % 48;
+                const int c = 32 * (k >> 4) + rho(k & 15, hf);
+                v = which == 0 ? p.ln1.gamma[c] : which == 1 ? p.ln1.beta[c] : which == 2 ? p.ln2.gamma[c] : which == 3 ? p.ln2.beta[c] : bia(p.fc2, c);
+            } else if (j < G::V_B1) {   // Q / K bias in accumulator order; K's spare row 13 is the constant 1 (the -max slot)
+                const int isk = j >= G::V_BK, k = j - (isk ? G::V_BK : G::V_BQ), vch = 32 * (k >> 4) + rho(k & 15, hf);
+                const int head = vch >> 4, c = vch & 15;
+                if (c < 12) v = isk ? bia(p.attn.k, head * 12 + c) : bia(p.attn.q, head * 12 + c) * qscale;
+                else if (isk && c == 13) v = 1.0f;
+            } else {
+                const int k = j - G::V_B1, hid = 32 * (k >> 4) + rho(k & 15, hf);
+                v = bia(p.fc1, hid) * kLog2e;
+            }
+        } else {   // V bias by virtual channel; spare row 12 is the constant 1 (softmax denominator)
+            const int vch = i - 2 * G::VHF, head = vch >> 4, c = vch & 15;
+            v = c < 12 ? bia(p.attn.v, head * 12 + c) : (c == 12 ? 1.0f : 0.f);
+        }
+        vec[i] = v;
+    }
+    // relative-position bias (a001:113-144), exp2 units: [query block][key tile][register / 4][lane][register % 4]
+    float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
+        const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, kt = (i >> 10) & 1, qb = i >> 11;
+        const int key = 32 * kt + rho(4 * a4 + j, lane >> 5), q = 32 * qb + (lane & 31);
+        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7, ws = a.ws, tw = 2 * ws - 1;
+        float v = 0.f;
+        if (ky >= ws || kx >= ws) v = -INFINITY;   // padding token of a 7x7 window as key: probability 0
+        else if (qy < ws && qx < ws) v = p.attn.bias_table[(ky - qy + ws - 1) * tw + (kx - qx + ws - 1)] * kLog2e;
+        bm[i] = v;
+    }
+}
+
+int num_cus96() {
+    static int n = [] {
+        int dev = 0, v = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
+        return v;
+    }();
+    return n;
+}
+
+}  // namespace
+
+bool win96_supported(const swf_block_desc& d) {
+    return d.attn.channels == 96 && d.attn.heads == 8 && d.attn.head_dim == 12 && d.attn.win_h == d.attn.win_w &&
+           (d.attn.win_h == 8 || d.attn.win_h == 7) && (d.hidden == 384 || d.hidden == 192);
+}
+
+size_t win96_packed_bytes(const swf_block_desc& d) {
+    if (!win96_supported(d)) return 0;
+    return align_up(d.hidden == 384 ? G96<384>::p_total : G96<192>::p_total, 256);
+}
+
+int pack_win96(const swf_block_desc& d, const swf_block_stream_params& px, const swf_block_stream_params& py, void* packed_x,
+               void* packed_y, hipStream_t stream) {
+    if (!win96_supported(d)) return fail(SWF_ERR_UNSUPPORTED, "pack_win96: shape not covered");
+    Pack96Args a;
+    a.p[0] = px; a.p[1] = py;
+    a.dst[0] = static_cast<char*>(packed_x); a.dst[1] = static_cast<char*>(packed_y);
+    a.ws = d.attn.win_h;
+    if (d.hidden == 384) hipLaunchKernelGGL((pack96_kernel<384>), dim3(128, 2), dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL((pack96_kernel<192>), dim3(128, 2), dim3(256), 0, stream, a);
+    return check_launch("pack_win96");
+}
+
+template <int HID, int WS>
+static int launch96_t(const Win96Args& a, int grid, hipStream_t stream) {
+    constexpr int lds = (int)G96<HID>::l_total;
+    static hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&window96_kernel<HID, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window96): %s", hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((window96_kernel<HID, WS>), dim3(grid), dim3(256), lds, stream, a);
+    return check_launch("window96");
+}
+
+int launch_win96(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,
+                 float* x_out, float* y_out, int B, int H, int W, hipStream_t stream, const void* next_packed_x,
+                 const void* next_packed_y, size_t next_bytes) {
+    const int wsd = d.attn.win_h;
+    if (!win96_supported(d) || H % wsd || W % wsd) return fail(SWF_ERR_UNSUPPORTED, "win96: shape not covered");
+    if ((int64_t)B * H * W * 96 * 4 >= (int64_t(1) << 31)) return fail(SWF_ERR_UNSUPPORTED, "win96: a stream of %d x %d x %d tokens exceeds the 2 GB buffer window", B, H, W);
+    Win96Args a;
+    a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
+    a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
+    a.warm[0] = static_cast<const char*>(next_packed_x); a.warm[1] = static_cast<const char*>(next_packed_y);
+    if (!a.warm[1]) a.warm[0] = nullptr;
+    a.warm_bytes = (int)(next_bytes ? next_bytes : win96_packed_bytes(d));
+    a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
+    const int nwin = B * (H / wsd) * (W / wsd);
+    const int grid = std::min(nwin, 2 * num_cus96());
+    if (wsd == 8) return d.hidden == 384 ? launch96_t<384, 8>(a, grid, stream) : launch96_t<192, 8>(a, grid, stream);
+    return d.hidden == 384 ? launch96_t<384, 7>(a, grid, stream) : launch96_t<192, 7>(a, grid, stream);
+}
+
+}  // namespace swf

@@ -21,6 +21,7 @@
 #include "kernels_window.h"
 #include "kernels_win24.h"
 #include "kernels_win48.h"
+#include "kernels_win96.h"
 
 #include <algorithm>
 #include <cstdlib>
@@ -1373,6 +1374,12 @@ static bool use_win48(const swf_block_desc& d) {
     return on && win48_supported(d);
 }
 
+// Level 2 (C = 96) likewise on kernels_win96.hip; SWF_WIN96=0 keeps the LDS-image kernel of this file
+static bool use_win96(const swf_block_desc& d) {
+    static const bool on = [] { const char* e = std::getenv("SWF_WIN96"); return !(e && e[0] == '0'); }();
+    return on && win96_supported(d);
+}
+
 static bool dims_match(const swf_block_desc& d, int C, int HID) {
     return d.attn.channels == C && d.hidden == HID && d.attn.heads == 8 && d.attn.head_dim * 8 == C && d.attn.win_h == d.attn.win_w &&
            (d.attn.win_h == 8 || d.attn.win_h == 7);
@@ -1382,6 +1389,7 @@ bool window_block_supported(const swf_block_desc& d, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return false;
     if (use_win24(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 24 * 4 < (int64_t(1) << 31);
     if (use_win48(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 48 * 4 < (int64_t(1) << 31);
+    if (use_win96(d) && H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 96 * 4 < (int64_t(1) << 31)) return true;
     if (H % d.attn.win_h || W % d.attn.win_w) return false;
 #define X(C, HID) if (dims_match(d, C, HID)) return true;
     SWF_WINDOW_SHAPES(X)
@@ -1392,6 +1400,7 @@ bool window_block_supported(const swf_block_desc& d, int B, int H, int W) {
 size_t window_block_packed_bytes(const swf_block_desc& d) {
     if (use_win24(d)) return win24_packed_bytes(d);
     if (use_win48(d)) return win48_packed_bytes(d);
+    if (use_win96(d)) return win96_packed_bytes(d);
 #define X(C, HID) if (dims_match(d, C, HID)) return align_up(Geo<C, HID>::p_total, 256);
     SWF_WINDOW_SHAPES(X)
 #undef X
@@ -1414,6 +1423,7 @@ int pack_window_block(const swf_block_desc& d, const swf_block_stream_params& px
                       void* packed_x, void* packed_y, hipStream_t stream) {
     if (use_win24(d)) return pack_win24(d, px, py, packed_x, packed_y, stream);
     if (use_win48(d)) return pack_win48(d, px, py, packed_x, packed_y, stream);
+    if (use_win96(d)) return pack_win96(d, px, py, packed_x, packed_y, stream);
     PackArgs a;
     a.p[0] = px; a.p[1] = py;
     a.dst[0] = static_cast<char*>(packed_x); a.dst[1] = static_cast<char*>(packed_y);
@@ -1446,6 +1456,7 @@ int launch_window_block(const swf_block_desc& d, const void* packed_x, const voi
                         const void* next_packed_x, const void* next_packed_y, size_t next_bytes) {
     if (use_win24(d)) return launch_win24(d, packed_x, packed_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_packed_x, next_packed_y, next_bytes);
     if (use_win48(d)) return launch_win48(d, packed_x, packed_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_packed_x, next_packed_y, next_bytes);
+    if (use_win96(d)) return launch_win96(d, packed_x, packed_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_packed_x, next_packed_y, next_bytes);
     WinArgs a;
     a.warm[0] = static_cast<const char*>(next_packed_x); a.warm[1] = static_cast<const char*>(next_packed_y);
     if (!a.warm[1]) a.warm[0] = nullptr;
