@@ -264,7 +264,7 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
             for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
                 for (int a = 0; a < 4; ++a) {
-                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((qb * 2 + kt) * 4 + a) * 1024, 0));
+                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((__builtin_amdgcn_readfirstlane(qb) * 2 + kt) * 4 + a) * 1024, 0));
                     bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
                 }
             const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
