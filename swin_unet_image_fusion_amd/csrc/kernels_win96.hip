@@ -38,6 +38,11 @@ struct G96 {
     static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
     // LDS: K images [stream 2][key tile 2][vch tile 4][k-step 2] x 1 KB, V^T images [stream 2][vch tile 4][pv-step 4] x 1 KB, vectors
     static constexpr size_t l_k = 0, l_v = 32 * 1024, l_vec = 64 * 1024, l_total = l_vec + size_t(2) * VSTREAM * 4;
+    // 16x16 windows (window96w16_kernel): bias tiles by key-tile / query-tile distance, fp32 [distance 15][reg/4 4][lane 64][4];
+    // LDS of ONE stream: K images [key tile 8][vch tile 4][k-step 2] x 1 KB, V^T images [vch tile 4][pv-step 16] x 1 KB, vectors
+    static constexpr size_t p_total16 = p_bias + size_t(15) * 16 * 64 * 4;
+    static constexpr size_t l_k16 = 0, l_v16 = 64 * 1024, l_vec16 = 128 * 1024, l_total16 = l_vec16 + size_t(2) * VSTREAM * 4;
+    static_assert(l_total16 <= 160 * 1024, "LDS");
 };
 
 struct Win96Args {
@@ -384,6 +389,324 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// 16x16 windows at C = 96 (BASELINE config 5, level 2): one workgroup = (window, stream) as in window48w16_kernel
+// (kernels_win48.hip) — the K / V^T images of 256 keys are 128 KB here, so one workgroup per CU, one wave per SIMD; a wave owns two
+// of the eight 32-token tiles.  Phase A per tile: LN1 of the own tokens (Q) and of the key / value stream's tokens (the other
+// stream's in a cross block, with THAT stream's LN1 parameters and this stream's K/V weights, a002:67-82), the 24 half phases of
+// window96_kernel; Q fragments stay in registers, K / V^T go to the images.  Phase B per tile: online softmax over four chunks of
+// 64 keys (attention96 as a chunk; running maximum kept as the f16 value the second S^T pass subtracts; bias tiles by tile
+// distance; row-seam chunks skipped, column seam = register bit 2 against lane bit 3), projection, LN2, MLP.  Not callable in
+// place in cross blocks (window_block_out_of_place).
+template <int HID>
+__global__ __launch_bounds__(256, 1) void window96w16_kernel(Win96Args args) {
+    using G = G96<HID>;
+    extern __shared__ __attribute__((aligned(16))) char smem96w[];
+    u32x4* kimg = reinterpret_cast<u32x4*>(smem96w + G::l_k16);   // [key tile][vch tile][k-step][lane]
+    u32x4* vimg = reinterpret_cast<u32x4*>(smem96w + G::l_v16);   // [vch tile][pv-step][lane]
+    float* lvec = reinterpret_cast<float*>(smem96w + G::l_vec16);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int ws = blockIdx.y, r = lane & 31, hf = lane >> 5;
+    const int H = args.H, W = args.W, nwx = W / 16, nwy = H / 16, npi = nwx * nwy;
+    const int nwin = args.B * npi;
+    const int sh = args.shift ? 8 : 0;
+    const int src = args.cross ? 1 - ws : ws;   // the stream whose tokens this stream's attention reads as keys / values
+
+    for (int i = tid; i < 2 * G::VSTREAM; i += 256)
+        lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(args.packed[ws]), 0, (int)G::p_total16, 0x00020000);
+    const int act_bytes = args.B * H * W * 96 * 4;   // < 2^31 (launch_win96)
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.in[ws]), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t srs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.in[src]), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(args.out[ws], 0, act_bytes, 0x00020000);
+    const unsigned loff = (unsigned)lane * 16u;
+    auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };
+    const float* vec = lvec + ws * G::VSTREAM + hf * G::VHF;        // own stream, own lane half (also the K bias: own weights)
+    const float* vecs = lvec + src * G::VSTREAM + hf * G::VHF;      // LN1 parameters of the key / value tokens' stream
+    const float* vecv = lvec + ws * G::VSTREAM + 2 * G::VHF;        // V bias [tile][32]
+    const bool half1 = hf != 0;
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        SWF_WF_FENCE();
+        const int b = win / npi, wrem = win - b * npi;
+        const int wy = wrem / nwx, wx = wrem - wy * nwx;
+        auto tokoff_of = [&](int j) {   // tile j = window rows 2j, 2j+1; the lane's token: row 2j + (r >> 4), column r & 15
+            int oy = wy * 16 + 2 * j + (r >> 4) + sh, ox = wx * 16 + (r & 15) + sh;
+            oy = oy >= H ? oy - H : oy;
+            ox = ox >= W ? ox - W : ox;
+            return (unsigned)((((b * H + oy) * W + ox) * 96 + 4 * hf) * 4);
+        };
+        auto load_rows = [&](const __amdgpu_buffer_rsrc_t& rs, unsigned tokoff, f32x16 (&x)[3]) {
+#pragma unroll
+            for (int a = 0; a < 12; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, tokoff, 32 * a, 0));
+                x[a >> 2][4 * (a & 3)] = v.x; x[a >> 2][4 * (a & 3) + 1] = v.y; x[a >> 2][4 * (a & 3) + 2] = v.z; x[a >> 2][4 * (a & 3) + 3] = v.w;
+            }
+        };
+
+        // ---- phase A: Q (registers), K and V^T (images) of the wave's two tiles ----
+        u32x4 qf[2][4][2];   // [tile of the wave][vch tile][k-step]
+#pragma unroll
+        for (int jj = 0; jj < 2; ++jj)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { qf[jj][T][0] = u32x4{0u, 0u, 0u, 0u}; qf[jj][T][1] = u32x4{0u, 0u, 0u, 0u}; }
+#pragma unroll 1
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * wave + jj;
+            const unsigned tokoff = tokoff_of(j);
+            u32x4 wq[2][6];
+            auto req = [&](int hp, u32x4 (&dst)[6]) {
+                const int f0 = G::F_QKV + ((hp >> 1) * 6 + 3 * (hp & 1)) * 2;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dst[i] = WF(f0 + i);
+            };
+            req(0, wq[0]);
+            u32x4 xh[6], xl[6], kh[6], kl[6];
+            {
+                f32x16 x[3];
+                load_rows(irs, tokoff, x);
+                layernorm96(x, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+                if (args.cross) {
+                    load_rows(srs, tokoff, x);
+                    layernorm96(x, vecs, G::V_LN1G, G::V_LN1B, kh, kl);
+                } else {
+#pragma unroll
+                    for (int s2 = 0; s2 < 6; ++s2) { kh[s2] = xh[s2]; kl[s2] = xl[s2]; }
+                }
+            }
+            // the finished tile's Q fragments rotate out of slot 1 (a runtime tile loop cannot index registers)
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { qf[0][T][0] = qf[1][T][0]; qf[0][T][1] = qf[1][T][1]; }
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int hp = 0; hp < 24; ++hp) {
+                const int m = hp >> 3, T = (hp >> 1) & 3, half = hp & 1;
+                SWF_WF_FENCE();
+                if (hp + 1 < 24) req(hp + 1, wq[(hp + 1) & 1]);
+                SWF_WF_FENCE();
+                const u32x4 (&w)[6] = wq[hp & 1];
+                if (half == 0) acc = zero16;
+#pragma unroll
+                for (int s2 = 0; s2 < 3; ++s2) {
+                    const int ks = 3 * half + s2;
+                    acc = m == 0 ? mma3(w[2 * s2], w[2 * s2 + 1], xh[ks], xl[ks], acc)
+                        : m == 1 ? mma3(w[2 * s2], w[2 * s2 + 1], kh[ks], kl[ks], acc)
+                                 : mma3(kh[ks], kl[ks], w[2 * s2], w[2 * s2 + 1], acc);
+                }
+                if (half == 1) {
+                    float t[16];
+                    if (m < 2) {
+                        const float* bsrc = m == 0 ? vec + G::V_BQ : vec + G::V_BK;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bb = *reinterpret_cast<const float4*>(bsrc + 16 * T + 4 * g);
+                            t[4 * g] = acc[4 * g] + bb.x; t[4 * g + 1] = acc[4 * g + 1] + bb.y; t[4 * g + 2] = acc[4 * g + 2] + bb.z; t[4 * g + 3] = acc[4 * g + 3] + bb.w;
+                        }
+                        if (m == 0) {
+                            qf[1][T][0] = pack8_f16(t);
+                            qf[1][T][1] = pack8_f16(t + 8);
+                        } else {
+                            u32x4* kdst = kimg + ((j * 4 + T) * 2) * 64 + lane;
+                            kdst[0] = pack8_f16(t);
+                            kdst[64] = pack8_f16(t + 8);
+                        }
+                    } else {
+                        const float bv = vecv[32 * T + r];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) t[i] = acc[i] + bv;
+                        u32x4* vdst = vimg + (T * 16 + 2 * j) * 64 + lane;
+                        vdst[0] = pack8_f16(t);
+                        vdst[64] = pack8_f16(t + 8);
+                    }
+                }
+            }
+        }
+        __syncthreads();   // K / V^T images of all 256 keys complete
+
+        // ---- phase B ----
+        const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
+#pragma unroll 1
+        for (int jj = 0; jj < 2; ++jj) {
+            const int j = 2 * wave + jj;   // query tile
+            const unsigned tokoff = tokoff_of(j);
+            f32x16 o[4] = {zero16, zero16, zero16, zero16};
+            float mrun[8];
+#pragma unroll
+            for (int h = 0; h < 8; ++h) mrun[h] = -INFINITY;
+#pragma unroll 1
+            for (int c = 0; c < 4; ++c) {
+                if (rowv && ((j < 4) != (c < 2))) continue;   // keys across the row seam: probabilities exactly 0
+                f32x16 bias[2];
+                {
+                    const int d0 = __builtin_amdgcn_readfirstlane(2 * c - j + 7);
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+                        for (int a = 0; a < 4; ++a) {
+                            const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((d0 + kt) * 4 + a) * 1024, 0));
+                            bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
+                        }
+                    if (colv) {
+                        const bool qhi = (r & 8) != 0;
+                        const float pen_lo = qhi ? -INFINITY : 0.f, pen_hi = qhi ? 0.f : -INFINITY;
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) {
+                            const float pen = ((i >> 2) & 1) ? pen_hi : pen_lo;
+                            bias[0][i] += pen; bias[1][i] += pen;
+                        }
+                    }
+                }
+                const u32x4* kc = kimg + (2 * c) * 8 * 64 + lane;   // key tiles 2c, 2c + 1: 8 fragments each
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int T = h >> 1, sp = h & 1;
+                    const u32x4 ka0 = kc[((0 * 4 + T) * 2 + sp) * 64], ka1 = kc[((1 * 4 + T) * 2 + sp) * 64];
+                    u32x4 qm = qf[0][T][sp];
+                    float mx;
+                    {
+                        f32x16 s0 = mfma_f16(ka0, qm, bias[0]);
+                        mx = max3f(s0[0], s0[1], s0[2]);
+#pragma unroll
+                        for (int i = 3; i < 15; i += 2) mx = max3f(mx, s0[i], s0[i + 1]);
+                        mx = __builtin_fmaxf(mx, s0[15]);
+                    }
+                    {
+                        f32x16 s1 = mfma_f16(ka1, qm, bias[1]);
+#pragma unroll
+                        for (int i = 0; i < 16; i += 2) mx = max3f(mx, s1[i], s1[i + 1]);
+                    }
+                    mx = max_halves(mx);
+                    const float mold = mrun[h];
+                    const f16 nm = (f16)(-__builtin_fmaxf(mold, mx));
+                    const float mnew = -(float)nm;   // the shift the second pass really applies
+                    const float alpha = __builtin_amdgcn_exp2f(mold - mnew);
+                    mrun[h] = mnew;
+                    qm[2] |= half1 ? ((unsigned)__builtin_bit_cast(unsigned short, nm) << 16) : 0u;
+                    f32x16 t;
+#pragma unroll
+                    for (int kt = 0; kt < 2; ++kt) {
+                        f32x16 sc = mfma_f16(kt ? ka1 : ka0, qm, bias[kt]);
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            float pe[8];
+#pragma unroll
+                            for (int e = 0; e < 8; ++e) pe[e] = __builtin_amdgcn_exp2f(sc[8 * s2 + e]);
+                            const u32x4 pf = pack8_f16(pe);
+                            const u32x4 va = vimg[(T * 16 + 4 * c + 2 * kt + s2) * 64 + lane];
+                            t = mfma_f16(va, pf, (kt == 0 && s2 == 0) ? zero16 : t);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) o[T][8 * sp + e] = __builtin_fmaf(o[T][8 * sp + e], alpha, t[8 * sp + e]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // the second tile's Q fragments move up
+#pragma unroll
+            for (int T = 0; T < 4; ++T) { qf[0][T][0] = qf[1][T][0]; qf[0][T][1] = qf[1][T][1]; }
+
+            // ---- normalise, output projection + bias + residual ----
+            f32x16 res[3];
+            u32x4 wp[2][6];
+            auto reqp = [&](int ks, u32x4 (&dst)[6]) {
+#pragma unroll
+                for (int To = 0; To < 3; ++To) { dst[2 * To] = WF(G::F_P + (To * 8 + ks) * 2); dst[2 * To + 1] = WF(G::F_P + (To * 8 + ks) * 2 + 1); }
+            };
+            SWF_WF_FENCE();
+            load_rows(irs, tokoff, res);
+            reqp(0, wp[0]);
+            SWF_WF_FENCE();
+            {
+                u32x4 oh[8], ol[8];
+#pragma unroll
+                for (int h = 0; h < 8; ++h) {
+                    const int T = h >> 1, sp = h & 1;
+                    float lo_, den;
+                    halves(o[T][8 * sp + 4], lo_, den);
+                    const float inv = __builtin_amdgcn_rcpf(den);
+                    float t[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) t[e] = o[T][8 * sp + e] * inv;
+                    split8(t, oh[h], ol[h]);
+                }
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks) {
+                    SWF_WF_FENCE();
+                    if (ks + 1 < 8) reqp(ks + 1, wp[(ks + 1) & 1]);
+                    SWF_WF_FENCE();
+                    const u32x4 (&w)[6] = wp[ks & 1];
+#pragma unroll
+                    for (int To = 0; To < 3; ++To) res[To] = mma3(w[2 * To], w[2 * To + 1], oh[ks], ol[ks], res[To]);
+                }
+            }
+            // ---- LN2, MLP ----
+            {
+                u32x4 xh[6], xl[6];
+                layernorm96(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+                u32x4 w1[12];
+                auto req1 = [&](int tI) {
+#pragma unroll
+                    for (int i = 0; i < 12; ++i) w1[i] = WF(G::F_W1 + tI * 12 + i);
+                };
+                req1(0);
+#pragma unroll 1
+                for (int tI = 0; tI < G::NT1; ++tI) {
+                    SWF_WF_FENCE();
+                    u32x4 w2[3][2][2];
+#pragma unroll
+                    for (int To = 0; To < 3; ++To)
+#pragma unroll
+                        for (int s2 = 0; s2 < 2; ++s2) {
+                            w2[To][s2][0] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2);
+                            w2[To][s2][1] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2 + 1);
+                        }
+                    SWF_WF_FENCE();
+                    f32x16 acc = zero16;
+#pragma unroll
+                    for (int s2 = 0; s2 < 6; ++s2) acc = mma3(w1[2 * s2], w1[2 * s2 + 1], xh[s2], xl[s2], acc);
+                    SWF_WF_FENCE();
+                    if (tI + 1 < G::NT1) req1(tI + 1);
+                    SWF_WF_FENCE();
+                    float e[16];
+#pragma unroll
+                    for (int g = 0; g < 4; ++g) {
+                        const float4 b1 = *reinterpret_cast<const float4*>(vec + G::V_B1 + 16 * tI + 4 * g);
+                        const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                        for (int jx = 0; jx < 4; ++jx) {
+                            const float u = acc[4 * g + jx] + bb[jx];
+                            const float L = __builtin_fmaf(__builtin_amdgcn_exp2f(u), kLog2e, -kLog2e);
+                            e[4 * g + jx] = __builtin_amdgcn_fmed3f(u, L, 0.f);
+                        }
+                    }
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        u32x4 hh, hl;
+                        split8(e + 8 * s2, hh, hl);
+#pragma unroll
+                        for (int To = 0; To < 3; ++To) res[To] = mma3(w2[To][s2][0], w2[To][s2][1], hh, hl, res[To]);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < 12; ++a) {
+                    const float4 b2 = *reinterpret_cast<const float4*>(vec + G::V_B2 + 4 * a);
+                    res[a >> 2][4 * (a & 3)] += b2.x; res[a >> 2][4 * (a & 3) + 1] += b2.y; res[a >> 2][4 * (a & 3) + 2] += b2.z; res[a >> 2][4 * (a & 3) + 3] += b2.w;
+                }
+            }
+#pragma unroll
+            for (int a = 0; a < 12; ++a) {
+                const f32x4 v = {res[a >> 2][4 * (a & 3)], res[a >> 2][4 * (a & 3) + 1], res[a >> 2][4 * (a & 3) + 2], res[a >> 2][4 * (a & 3) + 3]};
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, tokoff, 32 * a, 0);
+            }
+        }
+        __syncthreads();   // every wave is done with the images: the next window may overwrite them
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 struct Pack96Args {
     swf_block_stream_params p[2];
     char* dst[2];
@@ -459,6 +782,15 @@ __global__ __launch_bounds__(256) void pack96_kernel(Pack96Args a) {
     }
     // relative-position bias (a001:113-144), exp2 units: [query block][key tile][register / 4][lane][register % 4]
     float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    if (a.ws == 16) {   // [distance kt - qb + 7][register / 4][lane][register % 4]; a tile = two window rows of 16
+        for (int i = gtid; i < 15 * 16 * 64; i += gsz) {
+            const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, d = i >> 10;
+            const int key = rho(4 * a4 + j, lane >> 5), q = lane & 31;
+            const int dy = 2 * (d - 7) + (key >> 4) - (q >> 4), dx = (key & 15) - (q & 15);
+            bm[i] = p.attn.bias_table[(dy + 15) * 31 + (dx + 15)] * kLog2e;
+        }
+        return;
+    }
     for (int i = gtid; i < 2 * 2 * 16 * 64; i += gsz) {
         const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, kt = (i >> 10) & 1, qb = i >> 11;
         const int key = 32 * kt + rho(4 * a4 + j, lane >> 5), q = 32 * qb + (lane & 31);
@@ -483,11 +815,12 @@ int num_cus96() {
 
 bool win96_supported(const swf_block_desc& d) {
     return d.attn.channels == 96 && d.attn.heads == 8 && d.attn.head_dim == 12 && d.attn.win_h == d.attn.win_w &&
-           (d.attn.win_h == 8 || d.attn.win_h == 7) && (d.hidden == 384 || d.hidden == 192);
+           (d.attn.win_h == 8 || d.attn.win_h == 7 || d.attn.win_h == 16) && (d.hidden == 384 || d.hidden == 192);
 }
 
 size_t win96_packed_bytes(const swf_block_desc& d) {
     if (!win96_supported(d)) return 0;
+    if (d.attn.win_h == 16) return align_up(d.hidden == 384 ? G96<384>::p_total16 : G96<192>::p_total16, 256);
     return align_up(d.hidden == 384 ? G96<384>::p_total : G96<192>::p_total, 256);
 }
 
@@ -526,6 +859,17 @@ int launch_win96(const swf_block_desc& d, const void* packed_x, const void* pack
     a.warm_bytes = (int)(next_bytes ? next_bytes : win96_packed_bytes(d));
     a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
     const int nwin = B * (H / wsd) * (W / wsd);
+    if (wsd == 16) {   // 138 KB of LDS per workgroup: one per CU, grid.y = stream
+        static hipError_t attr_err = [] {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&window96w16_kernel<384>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G96<384>::l_total16);
+            return e != hipSuccess ? e : hipFuncSetAttribute(reinterpret_cast<const void*>(&window96w16_kernel<192>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)G96<192>::l_total16);
+        }();
+        if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window96w16): %s", hipGetErrorString(attr_err));
+        const int gx = std::min(nwin, (num_cus96() + 1) / 2);
+        if (d.hidden == 384) hipLaunchKernelGGL((window96w16_kernel<384>), dim3(gx, 2), dim3(256), G96<384>::l_total16, stream, a);
+        else hipLaunchKernelGGL((window96w16_kernel<192>), dim3(gx, 2), dim3(256), G96<192>::l_total16, stream, a);
+        return check_launch("window96w16");
+    }
     const int grid = std::min(nwin, 2 * num_cus96());
     if (wsd == 8) return d.hidden == 384 ? launch96_t<384, 8>(a, grid, stream) : launch96_t<192, 8>(a, grid, stream);
     return d.hidden == 384 ? launch96_t<384, 7>(a, grid, stream) : launch96_t<192, 7>(a, grid, stream);

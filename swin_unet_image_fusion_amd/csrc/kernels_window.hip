@@ -1410,7 +1410,7 @@ size_t window_block_packed_bytes(const swf_block_desc& d) {
 // The 16x16-window kernel at C = 48 runs one workgroup per (window, stream): in a cross block the workgroup of one stream reads the
 // other stream's tokens while that stream's workgroup writes its results, so the outputs must not alias the inputs.
 bool window_block_out_of_place(const swf_block_desc& d) {
-    return use_win48(d) && d.attn.win_h == 16;
+    return (use_win48(d) || use_win96(d)) && d.attn.win_h == 16;
 }
 
 size_t window_block_workspace_bytes(const swf_block_desc& d, int B, int H, int W) {
