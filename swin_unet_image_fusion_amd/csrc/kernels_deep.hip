@@ -367,7 +367,8 @@ DeepSizes deep_sizes(const swf_block_desc& d) {
 bool deep_block_supported(const swf_block_desc& d) {
     const int C = d.attn.channels, HD = d.attn.heads * d.attn.head_dim, hid = d.hidden;
     return d.precision == SWF_PREC_FAST && C >= 128 && C % 32 == 0 && HD % 32 == 0 && hid % 32 == 0 && C <= 1024 &&
-           attn_core_mfma_supported(d.attn.win_h, d.attn.win_w, d.attn.head_dim);
+           (attn_core_mfma_supported(d.attn.win_h, d.attn.win_w, d.attn.head_dim) ||
+            (attn_core_mfma16_supported(d.attn.win_h, d.attn.win_w, d.attn.head_dim) && d.attn.head_dim % 4 == 0));
 }
 
 static size_t deep_planes_bytes(const swf_block_desc& d) { return align_up((size_t)deep_sizes(d).total * 4, 256); }   // hi + lo planes, 2 bytes each

@@ -48,6 +48,8 @@ bool attn_core_mfma16_supported(int wh, int ww, int head_dim);
 size_t attn_core_mfma16_scratch_floats(int nprob);
 int launch_attn_core_mfma16(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
                             const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
-                            int heads, int head_dim, int shift, float* bias_scratch, hipStream_t stream);
+                            int heads, int head_dim, int shift, float* bias_scratch, hipStream_t stream, unsigned short* const* O_hi = nullptr,
+                            unsigned short* const* O_lo = nullptr, const unsigned short* const* Q16 = nullptr,
+                            const unsigned short* const* K16 = nullptr, const unsigned short* const* V16 = nullptr);   // 16-bit operand / plane variants: see launch_attn_core_mfma
 
 }  // namespace swf

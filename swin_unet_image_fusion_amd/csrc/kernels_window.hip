@@ -1024,6 +1024,8 @@ static int launch_attn_mfma_t(const AttnMfmaArgs& a, int ws, int nprob, hipStrea
 struct Attn16Args {
     const float* Q[2]; const float* K[2]; const float* V[2]; float* O[2];
     const float* table[2];    // relative-position bias table [(2*16-1)^2] per stream
+    unsigned short* Ohi[2]; unsigned short* Olo[2];   // non-null: O is written as split-bf16 planes (row stride ldo) instead
+    const unsigned short* Q16[2]; const unsigned short* K16[2]; const unsigned short* V16[2];   // non-null: Q (pre-scaled), K, V as f16 (deep-level GEMM epilogue)
     int ldq, ldk, ldv, ldo, B, H, W, heads, shift;
 };
 
@@ -1055,6 +1057,40 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
             kimg[tok * QS + c] = (f16)0.f;
         }
     }
+    bool staged16 = false;
+    if constexpr (VEC == 4) {
+        if (a.Q16[p]) {   // operands already in their 16-bit formats (deep-level Q/K/V GEMM epilogue): plain copies
+            staged16 = true;
+            uint2 q2[NIT], k2[NIT], v2[NIT];
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + it * 512;
+                if (e < NCHUNK) {
+                    const int tok = e / CPT, c0 = (e % CPT) * VEC;
+                    const int oy = (wy * WH + tok / WW + sh) % H, ox = (wx * WW + tok % WW + sw) % W;
+                    const int64_t t = ((int64_t)b * H + oy) * W + ox;
+                    q2[it] = *reinterpret_cast<const uint2*>(a.Q16[p] + t * a.ldq + head * D + c0);
+                    k2[it] = *reinterpret_cast<const uint2*>(a.K16[p] + t * a.ldk + head * D + c0);
+                    v2[it] = *reinterpret_cast<const uint2*>(a.V16[p] + t * a.ldv + head * D + c0);
+                }
+            }
+#pragma unroll
+            for (int it = 0; it < NIT; ++it) {
+                const int e = tid + it * 512;
+                if (e < NCHUNK) {
+                    const int tok = e / CPT, c0 = (e % CPT) * VEC;
+                    const int k16 = tok & 15;
+                    const int vpos = (tok & ~15) | (((k16 >> 2) & 1) << 3) | (((k16 >> 3) << 2) | (k16 & 3));
+                    *reinterpret_cast<uint2*>(qimg + tok * QS + c0) = q2[it];
+                    *reinterpret_cast<uint2*>(kimg + tok * QS + c0) = k2[it];
+                    const f16x4 v4 = __builtin_bit_cast(f16x4, v2[it]);
+#pragma unroll
+                    for (int j = 0; j < VEC; ++j) vt[(c0 + j) * VRS + vpos] = v4[j];
+                }
+            }
+        }
+    }
+    if (!staged16) {
     float qv[NIT][VEC], kv[NIT][VEC], vv[NIT][VEC];
 #pragma unroll
     for (int it = 0; it < NIT; ++it) {
@@ -1084,6 +1120,7 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
                 vt[(c0 + j) * VRS + vpos] = (f16)vv[it][j];
             }
         }
+    }
     }
     __syncthreads();
 
@@ -1156,6 +1193,31 @@ __global__ __launch_bounds__(512) void attn_core_mfma16_kernel(Attn16Args a) {
     l = (hf == LH) ? l : l_other;
     const float inv = 1.0f / l;
     const int oy = (wy * WH + q / WW + sh) % H, ox = (wx * WW + q % WW + sw) % W;
+    if constexpr (D % 4 == 0) {
+        if (a.Ohi[p]) {   // split-bf16 planes for the deep-level projection GEMM (kernels_deep.h)
+            const int64_t ooff = (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
+            bf16* hrow = reinterpret_cast<bf16*>(a.Ohi[p]) + ooff;
+            bf16* lrow = reinterpret_cast<bf16*>(a.Olo[p]) + ooff;
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    const int c = mt * 32 + 8 * (i >> 2) + 4 * hf;
+                    if (c < D) {
+                        bf16x4 hi, lo;
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            const float v = o[mt][i + j] * inv;
+                            hi[j] = (bf16)v;
+                            lo[j] = (bf16)(v - (float)hi[j]);
+                        }
+                        *reinterpret_cast<bf16x4*>(hrow + c) = hi;
+                        *reinterpret_cast<bf16x4*>(lrow + c) = lo;
+                    }
+                }
+            return;
+        }
+    }
     float* orow = a.O[p] + (((int64_t)b * H + oy) * W + ox) * a.ldo + head * D;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -1193,10 +1255,17 @@ size_t attn_core_mfma16_scratch_floats(int nprob) { (void)nprob; return 0; }
 
 int launch_attn_core_mfma16(const float* const* Q, const float* const* K, const float* const* V, float* const* O,
                             const float* const* table, int nprob, int ldq, int ldk, int ldv, int ldo, int B, int H, int W,
-                            int heads, int head_dim, int shift, float* bias_scratch, hipStream_t stream) {
+                            int heads, int head_dim, int shift, float* bias_scratch, hipStream_t stream, unsigned short* const* O_hi,
+                            unsigned short* const* O_lo, const unsigned short* const* Q16, const unsigned short* const* K16,
+                            const unsigned short* const* V16) {
     (void)bias_scratch;   // no longer used: the bias comes from the 31x31 table staged in LDS
     Attn16Args a{};
-    for (int i = 0; i < nprob; ++i) { a.Q[i] = Q[i]; a.K[i] = K[i]; a.V[i] = V[i]; a.O[i] = O[i]; a.table[i] = table[i]; }
+    if ((Q16 || O_hi) && (head_dim % 4 || ldq % 4 || ldk % 4 || ldv % 4)) return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma16: 16-bit operands need head_dim and strides %% 4 == 0");
+    for (int i = 0; i < nprob; ++i) {
+        a.Q[i] = Q ? Q[i] : nullptr; a.K[i] = K ? K[i] : nullptr; a.V[i] = V ? V[i] : nullptr; a.O[i] = O ? O[i] : nullptr; a.table[i] = table[i];
+        a.Ohi[i] = O_hi ? O_hi[i] : nullptr; a.Olo[i] = O_hi ? O_lo[i] : nullptr;
+        a.Q16[i] = Q16 ? Q16[i] : nullptr; a.K16[i] = Q16 ? K16[i] : nullptr; a.V16[i] = Q16 ? V16[i] : nullptr;
+    }
     a.ldq = ldq; a.ldk = ldk; a.ldv = ldv; a.ldo = ldo; a.B = B; a.H = H; a.W = W; a.heads = heads; a.shift = shift;
     switch (head_dim) {
         case 3: return launch_attn16_t<3>(a, nprob, stream);

@@ -322,8 +322,12 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         const bf16_raw* kk[2] = {qkv[0][1], qkv[1][1]};
         const bf16_raw* vv[2] = {qkv[0][2], qkv[1][2]};
         const float* tt[2] = {pp[0]->attn.bias_table, nstream == 2 ? pp[1]->attn.bias_table : nullptr};
-        SWF_TRY(launch_attn_core_mfma(nullptr, nullptr, nullptr, nullptr, tt, nstream, HD, HD, HD, HD, B, H, W, desc->attn.heads,
-                                      desc->attn.head_dim, desc->attn.shift, stream, o_hi, o_lo, qq, kk, vv, desc->attn.win_h));
+        if (desc->attn.win_h == 16)
+            SWF_TRY(launch_attn_core_mfma16(nullptr, nullptr, nullptr, nullptr, tt, nstream, HD, HD, HD, HD, B, H, W, desc->attn.heads,
+                                            desc->attn.head_dim, desc->attn.shift, nullptr, stream, o_hi, o_lo, qq, kk, vv));
+        else
+            SWF_TRY(launch_attn_core_mfma(nullptr, nullptr, nullptr, nullptr, tt, nstream, HD, HD, HD, HD, B, H, W, desc->attn.heads,
+                                          desc->attn.head_dim, desc->attn.shift, stream, o_hi, o_lo, qq, kk, vv, desc->attn.win_h));
     }
     SpGemmBatch gp{};
     gp.scratch = sk; gp.scratch_floats = sk_floats;

@@ -594,8 +594,9 @@ def test_nonsquare_batch3_vs_oracle(precision):
                                   (24, 3, 4, (3, 16, 48), False, True), (48, 6, 192, (2, 16, 32), True, False),
                                   (48, 6, 192, (1, 32, 48), True, True), (48, 6, 96, (2, 16, 16), True, True), (48, 6, 96, (1, 48, 32), False, False),
                                   (96, 12, 384, (1, 16, 16), True, True), (96, 12, 192, (2, 32, 16), True, False), (96, 12, 384, (1, 32, 48), False, True),
+                                  (192, 24, 768, (1, 32, 16), True, True), (192, 24, 384, (2, 16, 16), False, False),
                                   (384, 48, 1536, (1, 16, 16), False, True)],
-                         ids=["C24", "C24_plain_self", "C24_hid4_shift", "C24_onewin", "C24_hid4_cross", "C48", "C48_cross", "C48_hid96_onewin", "C48_hid96_plain", "C96_onewin", "C96_hid192_shift", "C96_plain_cross", "C384_onewin"])
+                         ids=["C24", "C24_plain_self", "C24_hid4_shift", "C24_onewin", "C24_hid4_cross", "C48", "C48_cross", "C48_hid96_onewin", "C48_hid96_plain", "C96_onewin", "C96_hid192_shift", "C96_plain_cross", "C192_deep_shift_cross", "C192_deep_hid384", "C384_onewin"])
 def test_window16_block_fast_vs_oracle(case):
     """16x16 windows (BASELINE config 5): the fast tier runs the MFMA attention core with online softmax over key
     tiles (256-token windows do not fit a score tile in LDS); checked against the oracle incl. a single-window map,
