@@ -752,6 +752,22 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
     const float* yi = y_in;
     const size_t pb = packed ? block_packed_bytes(*desc) : 0;
     bool ln1_ready = false;   // deep levels: block i's MLP reduce also writes block i+1's LN1 planes
+    // Kernels that cannot run a cross block in place (window_block_out_of_place): the two cross blocks ping-pong through two
+    // temporary maps at the END of the workspace (block 2: maps -> temporaries, block 3: temporaries -> outputs) instead of
+    // each going through basic_block_impl's temporary-and-copy route
+    float *tx = nullptr, *ty = nullptr;
+    size_t ws_left = workspace_bytes;
+    {
+        swf_block_desc dc = *desc;
+        dc.cross = 1;
+        const size_t map_bytes = (size_t)B * H * W * desc->attn.channels * 4;
+        if (desc->precision == SWF_PREC_FAST && py && window_block_supported(dc, B, H, W) && window_block_out_of_place(dc) && workspace &&
+            workspace_bytes >= 2 * map_bytes + 512 + 2 * window_block_packed_bytes(dc)) {
+            ws_left = (workspace_bytes - 2 * map_bytes) & ~size_t(255);
+            tx = reinterpret_cast<float*>(static_cast<char*>(workspace) + ws_left);
+            ty = tx + map_bytes / 4;
+        }
+    }
     for (int i = 0; i < 4; ++i) {
         swf_block_desc d = *desc;
         d.cross = i >= 2;          // self pair first, then cross pair (a012:72-73)
@@ -763,9 +779,11 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
         const swf_block_stream_params* nxt[2] = {i < 3 ? &px[i + 1] : nullptr, (i < 3 && py) ? &py[i + 1] : nullptr};
         if (equal_flags && d.cross && py)
             SWF_TRY(launch_all_equal(xi, yi, (int64_t)B * H * W * desc->attn.channels, equal_flags + (i - 2), stream));
-        SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, x_out, y_out, B, H, W, workspace, workspace_bytes, stream, pkx, pky,
+        float* xo = (tx && i == 2) ? tx : x_out;
+        float* yo = (tx && i == 2) ? ty : y_out;
+        SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, xo, yo, B, H, W, workspace, tx ? ws_left : workspace_bytes, stream, pkx, pky,
                                  nkx, nky, i == 3 ? after_pb : 0, i < 3 ? nxt : nullptr, &ln1_ready));
-        xi = x_out; yi = y_out;
+        xi = xo; yi = yo;
     }
     return SWF_OK;
 }
