@@ -173,8 +173,6 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
     const int sh = args.shift ? WS / 2 : 0;
     const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
 
-    for (int i = tid; i < 2 * G::VSTREAM; i += 256)
-        lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
     const int act_bytes = args.B * H * W * 48 * 4;   // < 2^31 (launch_win48)
@@ -189,7 +187,6 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
     const bool half1 = hf != 0;
     const bool col_masked = half1 != (((r >> 2) & 1) != 0);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
 
     for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
         SWF_WF_FENCE();
@@ -228,6 +225,14 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
             req(0, wq[0]);
             f32x16 x0, x1;
             load_rows(x0, x1);
+            if (win == (int)blockIdx.x) {
+                // the fp32 vectors of both streams -> LDS, once per launch: requested BEHIND the first window's rows and first
+                // weight fragments so that the three round trips overlap (at 512 windows a workgroup sees one or two windows:
+                // its prologue is on the critical path)
+                for (int i = tid; i < 2 * G::VSTREAM; i += 256)
+                    lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
+                __syncthreads();
+            }
             u32x4 xh[3], xl[3];
             layernorm48(x0, x1, vec, G::V_LN1G, G::V_LN1B, xh, xl);
             float t[16];
@@ -269,22 +274,20 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
                 }
             }
         }
+        // the bias tile of (stream, query block) is requested ahead of the barrier: its L2 round trip runs under the wait
+        f32x16 bias[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((__builtin_amdgcn_readfirstlane(qb) * 2 + kt) * 4 + a) * 1024, 0));
+                bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
+            }
         __syncthreads();   // K / V^T images of both streams complete
 
         // ---- attention of the wave's 32 queries, 8 heads (shift mask: kernels_win24.hip) ----
         f32x16 o[2];
         {
-            f32x16 bias[2];
-            {
-                const __amdgpu_buffer_rsrc_t& brs = wrs;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int a = 0; a < 4; ++a) {
-                        const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(brs, loff, (int)G::p_bias + ((__builtin_amdgcn_readfirstlane(qb) * 2 + kt) * 4 + a) * 1024, 0));
-                        bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
-                    }
-            }
             const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
             const u32x4* ksrc = kimg + (ws * 8) * 64 + lane;
             const u32x4* vsrc = vimg + (ws * 8) * 64 + lane;

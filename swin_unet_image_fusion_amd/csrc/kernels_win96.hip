@@ -160,8 +160,6 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
     const int sh = args.shift ? WS / 2 : 0;
     const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
 
-    for (int i = tid; i < 2 * G::VSTREAM; i += 256)
-        lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
     const int act_bytes = args.B * H * W * 96 * 4;   // < 2^31 (launch_win96)
@@ -176,7 +174,6 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
     const bool half1 = hf != 0;
     const bool col_masked = half1 != (((r >> 2) & 1) != 0);
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-    __syncthreads();
 
     for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
         SWF_WF_FENCE();
@@ -213,6 +210,14 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
             {
                 f32x16 x[3];
                 load_rows(x);
+                if (win == (int)blockIdx.x) {
+                    // the fp32 vectors of both streams -> LDS, once per launch: requested BEHIND the first window's rows and first
+                    // weight fragments so that the three round trips overlap (a launch of 256 windows is one window per workgroup:
+                    // its prologue is on the critical path)
+                    for (int i = tid; i < 2 * G::VSTREAM; i += 256)
+                        lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
+                    __syncthreads();
+                }
                 layernorm96(x, vec, G::V_LN1G, G::V_LN1B, xh, xl);
             }
             f32x16 acc = zero16;
@@ -259,19 +264,20 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
                 }
             }
         }
+        // the bias tile of (stream, query block) is requested ahead of the barrier: its L2 round trip runs under the wait
+        f32x16 bias[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((__builtin_amdgcn_readfirstlane(qb) * 2 + kt) * 4 + a) * 1024, 0));
+                bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
+            }
         __syncthreads();   // K / V^T images of both streams complete
 
         // ---- attention of the wave's 32 queries, 8 heads (shift mask: kernels_win24.hip) ----
         f32x16 o[4];
         {
-            f32x16 bias[2];
-#pragma unroll
-            for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                for (int a = 0; a < 4; ++a) {
-                    const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((__builtin_amdgcn_readfirstlane(qb) * 2 + kt) * 4 + a) * 1024, 0));
-                    bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
-                }
             const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
             const u32x4* ksrc = kimg + (ws * 16) * 64 + lane;
             const u32x4* vsrc = vimg + (ws * 16) * 64 + lane;
