@@ -292,8 +292,15 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
 
         // ---- normalise (denominator: lane half 1, register 8sp + 4 of the head's tile), output projection + bias + residual ----
         f32x16 res[3];
+        u32x4 wp[2][6];   // projection fragments of a k-step: [out tile][hi, lo]; two sets, the first requested under the normalisation
+        auto reqp = [&](int ks, u32x4 (&dst)[6]) {
+#pragma unroll
+            for (int To = 0; To < 3; ++To) { dst[2 * To] = WF(G::F_P + (To * 8 + ks) * 2); dst[2 * To + 1] = WF(G::F_P + (To * 8 + ks) * 2 + 1); }
+        };
         SWF_WF_FENCE();
         load_rows(res);
+        reqp(0, wp[0]);
+        SWF_WF_FENCE();
         {
             u32x4 oh[8], ol[8];   // k-step = head
 #pragma unroll
@@ -311,24 +318,25 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
 #pragma unroll
             for (int ks = 0; ks < 8; ++ks) {
                 SWF_WF_FENCE();
-                u32x4 wp[3][2];
+                if (ks + 1 < 8) reqp(ks + 1, wp[(ks + 1) & 1]);
+                SWF_WF_FENCE();
+                const u32x4 (&w)[6] = wp[ks & 1];
 #pragma unroll
-                for (int To = 0; To < 3; ++To) { wp[To][0] = WF(G::F_P + (To * 8 + ks) * 2); wp[To][1] = WF(G::F_P + (To * 8 + ks) * 2 + 1); }
-#pragma unroll
-                for (int To = 0; To < 3; ++To) res[To] = mma3(wp[To][0], wp[To][1], oh[ks], ol[ks], res[To]);
+                for (int To = 0; To < 3; ++To) res[To] = mma3(w[2 * To], w[2 * To + 1], oh[ks], ol[ks], res[To]);
             }
         }
 
         // ---- LN2, MLP: fc1 tile -> ELU -> split -> two k-steps of fc2 accumulating onto the residual ----
         {
-            u32x4 xh[6], xl[6];
-            layernorm96(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
             u32x4 w1[12];
             auto req1 = [&](int tI) {
 #pragma unroll
                 for (int i = 0; i < 12; ++i) w1[i] = WF(G::F_W1 + tI * 12 + i);
             };
-            req1(0);
+            req1(0);   // in flight during LN2
+            SWF_WF_FENCE();
+            u32x4 xh[6], xl[6];
+            layernorm96(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
 #pragma unroll 1
             for (int tI = 0; tI < G::NT1; ++tI) {
                 SWF_WF_FENCE();
