@@ -95,7 +95,8 @@ class ShardedFusion:
         with torch.cuda.stream(s):
             self.forward_fn(ir, vis)                  # warm-up on the capture stream (its own workspace)
             torch.cuda.synchronize()
-            with torch.cuda.graph(g, stream=s):
+            # thread_local: other threads of the process (the RCCL watchdog polls events) may call the runtime during the capture
+            with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 out = self.forward_fn(ir, vis)
         torch.cuda.current_stream(ir.device).wait_stream(s)
         self._graph, self._static, self.graph_active = g, (ir, vis, out), True
