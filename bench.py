@@ -59,7 +59,9 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     blk = model.encoder_list[0][3].self_att_block.shifted_window_block
     c = blk.in_out_dims
     mh, mw = model.merging_size
-    h, w = size // mh, size // mw
+    # the level-0 map as the model runs it: merged (reflect-padded to the merge size), then padded to a multiple of the window
+    wh, ww = blk.window_size
+    h, w = -(-(-(-size // mh)) // wh) * wh, -(-(-(-size // mw)) // ww) * ww
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device="cpu").manual_seed(7)
     x = torch.randn(batch, h, w, c, generator=g).to(dev)
