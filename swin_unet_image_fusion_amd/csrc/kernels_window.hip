@@ -1,23 +1,29 @@
-// Fused fast tier for gfx950 (MI355X): ONE launch = one BasicBlock (a005:127-145) for both modality
-// streams, for 8x8 windows and C in {24, 48, 96}.  Persistent workgroups walk the windows.  C = 24: 512 threads
-// (8 waves, 2 per SIMD), one workgroup per CU, weights resident in LDS, wave w owns 16 token rows of stream w>>2.
-// C = 48 / 96 (TT = 2): 256 threads, wave w owns 32 token rows of stream w>>1, weights come from L2 and every
-// fragment feeds two MFMAs; one workgroup per CU (one wave per SIMD, 512 registers, rotating MLP weight prefetch).
-// Every launch ends by touching the next block's packed weights (per-XCD L2 warm-up).  A wave keeps its rows for every per-token phase (LN1, Q/K/V, proj, LN2, MLP): the
-// residual rows live in registers in the MFMA output layout, loaded once from HBM (cyclic shift = index arithmetic)
-// and stored once.  Only attention mixes tokens and needs the two workgroup barriers per window.  HBM traffic per
-// block = read + write of each stream, nothing else.
+// Fast tier (include/swinfuse.h SWF_PREC_FAST), window-level kernels of gfx950 (MI355X).  This file holds
+//   * the dispatcher of the fused BasicBlock launch (a005:127-145, both streams): window_block_supported / packed_bytes /
+//     pack_window_block / launch_window_block route C = 24, 48, 96 to the register-resident kernels of kernels_win24.hip,
+//     kernels_win48.hip, kernels_win96.hip (8x8, 7x7 and 16x16 windows);
+//   * window_block_kernel<C, HID, TT>, the round-1 design those kernels replaced (activations as split-bf16 LDS images, one
+//     workgroup per CU at C = 96): kept as the A/B fallback behind SWF_WIN24=0 / SWF_WIN48=0 / SWF_WIN96=0 (8x8 and 7x7 windows);
+//   * the stand-alone MFMA attention cores on projection buffers: attn_core_mfma_kernel<D, WS> (8x8 / 7x7 windows: the deep
+//     levels' core) and attn_core_mfma16_kernel<D> (16x16 windows, online softmax over key tiles), both with optional 16-bit
+//     operand inputs and split-plane output for the deep-level GEMM path (kernels_deep.hip);
+//   * l2_warm_kernel.
 //
-// Arithmetic (include/swinfuse.h SWF_PREC_FAST; error budget measured in DESIGN.md):
-//   linear layers : split-bf16 "bf16x3" on v_mfma_f32_16x16x32_bf16 — a = a_hi + a_lo, w = w_hi + w_lo,
-//                   a.w ~= a_lo.w_hi + a_hi.w_lo + a_hi.w_hi, fp32 accumulate (~2^-17 relative: fp32-grade;
-//                   plain bf16 linears miss the 1e-3 parity gate by 4-10x, gfx950 has no xf32/tf32)
-//   Q.K^T         : bf16 on v_mfma_f32_32x32x16_bf16, computed swapped (S^T = K.Q^T) so a lane owns one
-//                   query column: softmax max/sum are in-lane + one cross-half exchange
-//   P.V           : fp16 on v_mfma_f32_32x32x16_f16; the S^T accumulator tile converts in registers to the
-//                   B operand of O^T = V^T.P^T (no LDS round trip; V^T is stored in the matching k order)
+// Arithmetic (error budget measured in DESIGN.md):
+//   linear layers : split-bf16 "bf16x3" MFMA — a = a_hi + a_lo, w = w_hi + w_lo, a.w ~= a_lo.w_hi + a_hi.w_lo + a_hi.w_hi,
+//                   fp32 accumulate (~2^-17 relative: fp32-grade; plain bf16 linears miss the 1e-3 parity gate by 4-10x,
+//                   gfx950 has no xf32/tf32)
+//   Q.K^T, P.V    : f16 on v_mfma_f32_32x32x16_f16, computed swapped (S^T = K.Q^T) so a lane owns one query column: softmax
+//                   max / sum are in-lane + one cross-half exchange; the S^T accumulator tile converts in registers to the B
+//                   operand of O^T = V^T.P^T (V^T stored in the matching k order)
 //   LayerNorm statistics, bias, mask, softmax, ELU, residual stream, accumulators: fp32.
 //   exp() runs as v_exp_f32 (exp2): Wq/bq carry d^-0.5*log2(e), the bias matrices carry log2(e).
+//
+// window_block_kernel in short: persistent workgroups walk the windows; a wave keeps its token rows for every per-token phase
+// (LN1, Q/K/V, proj, LN2, MLP) with the residual rows in registers in the MFMA output layout; only attention mixes tokens
+// (two workgroup barriers per window); weights stream from L2, every fragment feeding two MFMAs at TT = 2 (32 tokens per
+// wave); every launch ends by touching the next block's packed weights (per-XCD L2 warm-up).  The SWF_* macros below select
+// the layouts that shipped in round 1 (their alternatives are the measured-and-rejected variants of DESIGN.md Appendix A).
 #include "kernels_window.h"
 #include "kernels_win24.h"
 #include "kernels_win48.h"
