@@ -302,8 +302,12 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
 
         // ---- normalise (denominator: lane half 1, register 4q+2), output projection + bias + residual ----
         f32x16 res0, res1;
+        u32x4 wpj[16];   // all 16 projection fragments ([out tile 2][k-step 4][hi, lo]): requested here, in flight under the normalisation
         SWF_WF_FENCE();
         load_rows(res0, res1);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) wpj[i] = WF(G::F_P + i);
+        SWF_WF_FENCE();
         {
             u32x4 oh[4], ol[4];
 #pragma unroll
@@ -320,11 +324,10 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
                 split8(t, oh[2 * T], ol[2 * T]);
                 split8(t + 8, oh[2 * T + 1], ol[2 * T + 1]);
             }
-            SWF_WF_FENCE();
 #pragma unroll
             for (int ks = 0; ks < 4; ++ks) {
-                res0 = mma3(WF(G::F_P + (0 * 4 + ks) * 2), WF(G::F_P + (0 * 4 + ks) * 2 + 1), oh[ks], ol[ks], res0);
-                res1 = mma3(WF(G::F_P + (1 * 4 + ks) * 2), WF(G::F_P + (1 * 4 + ks) * 2 + 1), oh[ks], ol[ks], res1);
+                res0 = mma3(wpj[(0 * 4 + ks) * 2], wpj[(0 * 4 + ks) * 2 + 1], oh[ks], ol[ks], res0);
+                res1 = mma3(wpj[(1 * 4 + ks) * 2], wpj[(1 * 4 + ks) * 2 + 1], oh[ks], ol[ks], res1);
             }
         }
 
