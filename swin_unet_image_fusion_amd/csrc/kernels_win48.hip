@@ -339,21 +339,27 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
 #pragma unroll
                 for (int i = 0; i < 6; ++i) dst[i] = WF(G::F_W1 + tI * 6 + i);
             };
+            // fc2 fragments of a hidden tile ([out tile][k-step of the tile][hi, lo]) are requested one tile ahead as well: asked
+            // for at the top of their own tile they arrived ~0.5 us after the fc1 MFMAs and ELU had finished (ablation: the six
+            // MLP tiles took 17 of the launch's 50 us at two waves per SIMD, three times their issue time)
+            u32x4 w2[2][2][2][2];
+            auto req2 = [&](int tI, u32x4 (&dst)[2][2][2]) {
+#pragma unroll
+                for (int To = 0; To < 2; ++To)
+#pragma unroll
+                    for (int s2 = 0; s2 < 2; ++s2) {
+                        dst[To][s2][0] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2);
+                        dst[To][s2][1] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2 + 1);
+                    }
+            };
             req1(0, w1[0]);
+            req2(0, w2[0]);
             u32x4 xh[3], xl[3];
             layernorm48(res0, res1, vec, G::V_LN2G, G::V_LN2B, xh, xl);
 #pragma unroll
             for (int tI = 0; tI < G::NT1; ++tI) {
                 SWF_WF_FENCE();
-                u32x4 w2[2][2][2];   // [out tile][k-step of this hidden tile][hi, lo]
-#pragma unroll
-                for (int To = 0; To < 2; ++To)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        w2[To][s2][0] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2);
-                        w2[To][s2][1] = WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2 + 1);
-                    }
-                if (tI + 1 < G::NT1) req1(tI + 1, w1[(tI + 1) & 1]);
+                if (tI + 1 < G::NT1) { req1(tI + 1, w1[(tI + 1) & 1]); req2(tI + 1, w2[(tI + 1) & 1]); }
                 SWF_WF_FENCE();
                 const u32x4 (&w)[6] = w1[tI & 1];
                 f32x16 acc = zero16;
@@ -375,8 +381,8 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
                 for (int s2 = 0; s2 < 2; ++s2) {
                     u32x4 hh, hl;
                     split8(e + 8 * s2, hh, hl);
-                    res0 = mma3(w2[0][s2][0], w2[0][s2][1], hh, hl, res0);
-                    res1 = mma3(w2[1][s2][0], w2[1][s2][1], hh, hl, res1);
+                    res0 = mma3(w2[tI & 1][0][s2][0], w2[tI & 1][0][s2][1], hh, hl, res0);
+                    res1 = mma3(w2[tI & 1][1][s2][0], w2[tI & 1][1][s2][1], hh, hl, res1);
                 }
                 __builtin_amdgcn_sched_barrier(0);   // one hidden tile at a time
             }
