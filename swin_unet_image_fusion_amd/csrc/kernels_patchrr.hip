@@ -46,7 +46,8 @@ __global__ __launch_bounds__(256) void patch_rr_kernel(PrrArgs a) {
     __shared__ float lvec[3 * 2 * NV];
     const int s = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hf = lane >> 5;
-    for (int i = tid; i < 3 * 2 * NV; i += 256) lvec[i] = reinterpret_cast<const float*>(a.packed[s] + P::p_vec)[i];
+    // (all loads before the first store: win_frag.h fill_vectors; the two "streams" here are the two halves of the one section)
+    fill_vectors<3 * NV / 4, 256>(lvec, a.packed[s] + P::p_vec, a.packed[s] + P::p_vec + (3 * NV / 4) * 16, tid);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(a.packed[s]), 0, (int)P::p_total, 0x00020000);
     const unsigned loff = (unsigned)lane * 16u;
     auto WA = [&](int nt, int ks, int hl) {

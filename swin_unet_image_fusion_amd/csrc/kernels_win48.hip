@@ -229,8 +229,8 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
                 // the fp32 vectors of both streams -> LDS, once per launch: requested BEHIND the first window's rows and first
                 // weight fragments so that the three round trips overlap (at 512 windows a workgroup sees one or two windows:
                 // its prologue is on the critical path)
-                for (int i = tid; i < 2 * G::VSTREAM; i += 256)
-                    lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
+                static_assert(G::VSTREAM % 4 == 0 && G::p_vec % 16 == 0, "vector sections move as 16-byte groups");
+                    fill_vectors<G::VSTREAM / 4, 256>(lvec, args.packed[0] + G::p_vec, args.packed[1] + G::p_vec, tid);
                 __syncthreads();
             }
             u32x4 xh[3], xl[3];
@@ -439,8 +439,8 @@ __global__ __launch_bounds__(256, 2) void window48w16_kernel(Win48Args args) {
     const int sh = args.shift ? 8 : 0;
     const int src = args.cross ? 1 - ws : ws;   // the stream whose tokens this stream's attention reads as keys / values
 
-    for (int i = tid; i < 2 * G::VSTREAM; i += 256)
-        lvec[i] = reinterpret_cast<const float*>(args.packed[i / G::VSTREAM] + G::p_vec)[i % G::VSTREAM];
+    static_assert(G::VSTREAM % 4 == 0 && G::p_vec % 16 == 0, "vector sections move as 16-byte groups");
+                    fill_vectors<G::VSTREAM / 4, 256>(lvec, args.packed[0] + G::p_vec, args.packed[1] + G::p_vec, tid);
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(args.packed[ws]), 0, (int)G::p_total16, 0x00020000);
     const int act_bytes = args.B * H * W * 48 * 4;   // < 2^31 (launch_win48)
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(args.in[ws]), 0, act_bytes, 0x00020000);

@@ -75,6 +75,26 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
     return reinterpret_cast<T*>(((unsigned long long)hi << 32) | lo);
 }
 
+
+// Copy the fp32 vector sections of the two streams' packed images (n4 16-byte groups each) into LDS with every load of a thread
+// issued before its first store.  (The obvious strided loop "lvec[i] = src[i]" runs one dependent global round trip per iteration:
+// at 1 248 floats per stream that was 20 us of a 48-us launch — stamped with wall_clock64, DESIGN.md.)
+template <int N4, int NTHREADS>
+__device__ __forceinline__ void fill_vectors(float* lvec, const char* vec0, const char* vec1, int tid) {
+    constexpr int PER = (2 * N4 + NTHREADS - 1) / NTHREADS;
+    f32x4 tmp[PER];
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = tid + NTHREADS * k;
+        if (idx < 2 * N4) tmp[k] = reinterpret_cast<const f32x4*>(idx < N4 ? vec0 : vec1)[idx < N4 ? idx : idx - N4];
+    }
+#pragma unroll
+    for (int k = 0; k < PER; ++k) {
+        const int idx = tid + NTHREADS * k;
+        if (idx < 2 * N4) reinterpret_cast<f32x4*>(lvec)[idx] = tmp[k];
+    }
+}
+
 }  // namespace wf
 }  // namespace swf
 
