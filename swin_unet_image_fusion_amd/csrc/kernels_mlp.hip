@@ -2,7 +2,7 @@
 //   out = x + fc2(ELU(fc1(LN2(x))))            per stream, C in {128, 192, 256, 384}, hidden % 128 == 0.
 // Replaces LayerNorm + fc1 GEMM + fc2 GEMM (+ split-K reduce) and the round trip of the hidden activations.
 //
-// grid = (64-token tiles, hidden splits, streams), 256 threads = 4 waves.  A workgroup normalises its 64 token rows
+// grid = (64-token tiles, hidden splits, streams), 256 threads = 4 waves (C = 384: 512 threads = 8 waves on a 256-wide chunk).  A workgroup normalises its 64 token rows
 // once (LN2, fp32, two shuffles per row) into a split-bf16 LDS image, then walks its hidden range in chunks of 128:
 //   fc1   wave w owns hidden rows [32w, 32w+32) of the chunk for all 64 tokens: H^T = W1 . xn^T on v_mfma_f32_32x32x16_bf16
 //         (bf16x3: lo.hi + hi.lo + hi.hi, fp32 accumulate), + bias, ELU, split -> LDS image H [64][128] hi / lo
@@ -24,7 +24,10 @@
 
 #ifdef SWF_MLP_PROBE   // tools/mlp_probe.hip: wall-clock stamps of workgroup (0,0,0) wave 0 at the phase boundaries
 __device__ unsigned long long swf_mlp_probe[64];
-#define SWF_PROBE(i) do { if (blockIdx.x == SWF_MLP_PROBE && blockIdx.y == 0 && blockIdx.z == 0 && threadIdx.x == 0) swf_mlp_probe[i] = wall_clock64(); } while (0)
+__device__ unsigned long long swf_mlp_wg[2 * 4096];   // entry / exit stamp of every workgroup (stamps 0 and 41)
+#define SWF_PROBE(i) do { if (threadIdx.x == 0) { const unsigned long long t_ = wall_clock64(); \
+        if (blockIdx.x == SWF_MLP_PROBE && blockIdx.y == 0 && blockIdx.z == 0) swf_mlp_probe[i] = t_; \
+        if ((i) == 0 || (i) == 41) swf_mlp_wg[2 * (((blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) & 4095) + ((i) == 41)] = t_; } } while (0)
 #else
 #define SWF_PROBE(i) do { } while (0)
 #endif
@@ -61,23 +64,29 @@ __device__ __forceinline__ void mma3(f32x16& acc, const bf16x8 wh, const bf16x8 
     acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh, bh, acc, 0, 0, 0);
 }
 
-template <int C>
-__global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
+// NW waves per workgroup = a hidden chunk of CW = 32 NW.  NW = 8 (C = 384): two waves per SIMD, each streaming its own fragments
+// (the per-wave vector-memory rate, not L2, bounds the 4-wave kernel: DESIGN A.3), ONE 256-wide chunk per workgroup with the H image
+// laid over the A image once fc1 has read it (A + H side by side would need 168 KB).
+template <int C, int NW>
+__global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
+    constexpr int NT = 64 * NW, CW = 32 * NW, TPR = NT / 64;   // threads, hidden chunk width, threads per token row
     constexpr int KS1 = C / 16;                  // k16 steps of fc1
     constexpr int T = C / 32;                    // 32-channel output tiles of fc2
-    static_assert(T % 4 == 0 || T % 4 == 2, "C must be a multiple of 64");
-    constexpr int NF = (T - T % 4) / 4;          // whole tiles per wave
-    constexpr int NH = (T % 4) ? 1 : 0;          // + one half tile (one 32-token half)
+    constexpr int NF = T / NW, R = T % NW;       // whole tiles per wave; the R left-over tiles are dealt as 2R halves
+    static_assert(R == 0 || 2 * R == NW, "the left-over output tiles must deal out as one half tile per wave");
+    constexpr int NH = R ? 1 : 0;                // + one half tile (one 32-token half)
     constexpr int NFR = NF + NH;                 // W2 fragments per k16 step
-    constexpr int KS2 = 8;                       // k16 steps per 128-wide hidden chunk
+    constexpr int KS2 = CW / 16;                 // k16 steps per hidden chunk
     constexpr int NFRAG = KS1 + KS2 * NFR;       // weight fragments a wave streams per chunk
-    constexpr int D = (NFRAG % 16 == 0) ? 16 : 14;   // ring depth: ~1 us of MFMA work ahead (L2 / MALL latency under load)
+    constexpr int D = NW == 8 ? 8 : (NFRAG % 16 == 0) ? 16 : 14;   // ring depth: ~1 us of MFMA work ahead (L2 / MALL latency under load)
     static_assert(NFRAG % D == 0, "ring depth must divide the fragment count");
-    constexpr int LDA = C + 8, LDH = 128 + 8;    // row strides (bf16): odd multiples of 16 B
+    constexpr bool ALIAS = NW == 8;              // H over A: one chunk per workgroup (launch_c checks)
+    constexpr int LDA = C + 8, LDH = CW + 8;     // row strides (bf16): odd multiples of 16 B
+    static_assert(!ALIAS || LDH <= LDA, "the H image must fit the A image");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16* a_hi = reinterpret_cast<bf16*>(smem);
     bf16* a_lo = a_hi + 64 * LDA;
-    bf16* h_hi = a_lo + 64 * LDA;
+    bf16* h_hi = ALIAS ? a_hi : a_lo + 64 * LDA;
     bf16* h_lo = h_hi + 64 * LDH;
 
     const int tile = blockIdx.x, split = blockIdx.y, s = blockIdx.z;
@@ -88,63 +97,68 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
     // ---- the wave's weight fragment stream: per chunk KS1 fragments of W1 (its 32 hidden rows), then per k16 step of
     //      fc2 one fragment per output tile it owns.  The planes are fragment-major (DeepWeights): a fragment is one
     //      contiguous 1-KB block, lane l reads bytes [16l, 16l+16) ----
-    const bf16* w1h = a.w1_hi[s] + lane * 8;
-    const bf16* w1l = a.w1_lo[s] + lane * 8;
-    const bf16* w2h = a.w2_hi[s] + lane * 8;
-    const bf16* w2l = a.w2_lo[s] + lane * 8;
-    const int half_nt = T - 2 + (wave >> 1), half_tok = wave & 1;
+    // (buffer loads: lane offset in one VGPR, the fragment's byte offset in an SGPR — per-fragment 64-bit addresses cost the
+    //  8-wave kernel 70 spilled registers and the 4-wave ones 60-230 AGPRs)
+    const unsigned wbytes = (unsigned)C * (unsigned)HID * 2u;
+    const __amdgpu_buffer_rsrc_t r1h = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w1_hi[s]), 0, (int)wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r1l = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w1_lo[s]), 0, (int)wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2h = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w2_hi[s]), 0, (int)wbytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r2l = __builtin_amdgcn_make_buffer_rsrc(const_cast<bf16*>(a.w2_lo[s]), 0, (int)wbytes, 0x00020000);
+    const int loff = lane * 16;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const int half_nt = T - R + (wave >> 1), half_tok = wave & 1;
     const int KSH = HID / 16;   // k16 steps of a whole W2 row
     int w2blk[NFR];             // first block of the W2 row tile
 #pragma unroll
-    for (int j = 0; j < NFR; ++j) w2blk[j] = (j < NF ? wave + 4 * j : half_nt) * KSH;
+    for (int j = 0; j < NFR; ++j) w2blk[j] = (j < NF ? wave_u + NW * j : T - R + (wave_u >> 1)) * KSH;
 
     bf16x8 rh[D], rl[D];
     // fragment f (0 <= f < NFRAG after unrolling: a constant) of the chunk with hidden base hb -> ring slot f % D
     auto frag_load = [&](int f, int hb) {
         if (f < KS1) {
-            const int64_t blk = (int64_t)((hb >> 5) + wave) * KS1 + f;
-            rh[f % D] = *reinterpret_cast<const bf16x8*>(w1h + blk * 512);
-            rl[f % D] = *reinterpret_cast<const bf16x8*>(w1l + blk * 512);
+            const int off = (((hb >> 5) + wave_u) * KS1 + f) * 1024;
+            rh[f % D] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r1h, loff, off, 0));
+            rl[f % D] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r1l, loff, off, 0));
         } else {
             const int q = f - KS1, ks = q / NFR, j = q % NFR;
-            const int64_t blk = w2blk[j] + (hb >> 4) + ks;
-            rh[f % D] = *reinterpret_cast<const bf16x8*>(w2h + blk * 512);
-            rl[f % D] = *reinterpret_cast<const bf16x8*>(w2l + blk * 512);
+            const int off = (w2blk[j] + (hb >> 4) + ks) * 1024;
+            rh[f % D] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r2h, loff, off, 0));
+            rl[f % D] = __builtin_bit_cast(bf16x8, __builtin_amdgcn_raw_buffer_load_b128(r2l, loff, off, 0));
         }
     };
 
     SWF_PROBE(0);
-    const int hb0 = split * a.nchunks * 128;
+    const int hb0 = split * a.nchunks * CW;
     // ---- LN2 of the 64 token rows -> split-bf16 image (4 threads per row).  Vector memory returns in order, so the token
     //      rows (and gamma / beta, which travel through the idle H buffer) are requested BEFORE the weight ring's first D
     //      fragments: the ring then fills during the LayerNorm arithmetic instead of delaying it (3.1 -> 1.x us at C=192). ----
     {
-        const int row = tid >> 2, sub = tid & 3;
+        const int row = tid / TPR, sub = tid % TPR;
         const int m = min(tile * 64 + row, a.M - 1);   // rows past M are computed on a clamped copy and never stored
         const float* xr = a.x[s] + (int64_t)m * C;
-        constexpr int NV = C / 16;
+        constexpr int NV = C / (4 * TPR), CS = 4 * TPR;   // float4s per thread, column step
         float4 v[NV];
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + 16 * i + 4 * sub);
+        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + CS * i + 4 * sub);
         if (a.part0[s]) {   // attention residual: x + proj bias + the two head-group partials of the projection, fixed order
             const float* p0 = a.part0[s] + (int64_t)m * C;
             const float* p1 = a.part1[s] + (int64_t)m * C;
             float4 u0[NV], u1[NV];
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                u0[i] = *reinterpret_cast<const float4*>(p0 + 16 * i + 4 * sub);
-                u1[i] = *reinterpret_cast<const float4*>(p1 + 16 * i + 4 * sub);
+                u0[i] = *reinterpret_cast<const float4*>(p0 + CS * i + 4 * sub);
+                u1[i] = *reinterpret_cast<const float4*>(p1 + CS * i + 4 * sub);
             }
             const bool wr = split == 0 && tile * 64 + row < a.M;
 #pragma unroll
             for (int i = 0; i < NV; ++i) {
-                const float4 pb = *reinterpret_cast<const float4*>(a.pbias[s] + 16 * i + 4 * sub);
+                const float4 pb = *reinterpret_cast<const float4*>(a.pbias[s] + CS * i + 4 * sub);
                 v[i].x = ((v[i].x + pb.x) + u0[i].x) + u1[i].x; v[i].y = ((v[i].y + pb.y) + u0[i].y) + u1[i].y;
                 v[i].z = ((v[i].z + pb.z) + u0[i].z) + u1[i].z; v[i].w = ((v[i].w + pb.w) + u0[i].w) + u1[i].w;
-                if (wr) *reinterpret_cast<float4*>(a.x1[s] + (int64_t)m * C + 16 * i + 4 * sub) = v[i];
+                if (wr) *reinterpret_cast<float4*>(a.x1[s] + (int64_t)m * C + CS * i + 4 * sub) = v[i];
             }
         }
-        float* gb = reinterpret_cast<float*>(h_hi);   // [2][C] fp32: gamma, beta
+        float* gb = reinterpret_cast<float*>(ALIAS ? a_lo + 64 * LDA : h_hi);   // [2][C] fp32: gamma, beta
         float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < C / 2) gbv = *reinterpret_cast<const float4*>((tid < C / 4 ? a.gamma[s] : a.beta[s] - C) + 4 * tid);
         __builtin_amdgcn_sched_barrier(0);
@@ -157,6 +171,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         sum += __shfl_xor(sum, 1);
         sum += __shfl_xor(sum, 2);
+        if constexpr (TPR == 8) sum += __shfl_xor(sum, 4);
         const float mean = sum * (1.0f / C);
         float var = 0.f;
 #pragma unroll
@@ -166,11 +181,12 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         }
         var += __shfl_xor(var, 1);
         var += __shfl_xor(var, 2);
+        if constexpr (TPR == 8) var += __shfl_xor(var, 4);
         const float rstd = 1.0f / sqrtf(var * (1.0f / C) + 1e-5f);
         __syncthreads();   // gamma / beta are in LDS
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int c = 16 * i + 4 * sub;
+            const int c = CS * i + 4 * sub;
             const float4 gm = *reinterpret_cast<const float4*>(gb + c), bt = *reinterpret_cast<const float4*>(gb + C + c);
             const float n[4] = {(v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y,
                                 (v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w};
@@ -191,10 +207,10 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
 
     for (int ch = 0; ch < a.nchunks; ++ch) {
-        const int hb = hb0 + ch * 128;
+        const int hb = hb0 + ch * CW;
         // next chunk's hidden base for the ring's run-ahead; past the last chunk the ring re-reads this chunk's first
         // fragments (dead loads) instead of branching: a conditional prefetch costs the counted waits their count
-        const int hbn = ch + 1 < a.nchunks ? hb + 128 : hb;
+        const int hbn = ch + 1 < a.nchunks ? hb + CW : hb;
         // ---- fc1: H^T[32 hidden of this wave][64 tokens] ----
         f32x16 acc1[2];
 #pragma unroll
@@ -230,6 +246,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         SWF_PROBE(2 + 4 * (ch & 7));
+        if constexpr (ALIAS) __syncthreads();   // every wave has read its last A fragments: the H image may overwrite them
         // bias, ELU, split: register 4g+j of token half t is hidden 32w + 8g + 4hf + j of token 32t + r
 #pragma unroll
         for (int t = 0; t < 2; ++t)
@@ -308,7 +325,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
     float* otile = reinterpret_cast<float*>(smem);
 #pragma unroll
     for (int i = 0; i < 2 * NF + NH; ++i) {
-        const int nt = i < 2 * NF ? wave + 4 * (i >> 1) : half_nt;
+        const int nt = i < 2 * NF ? wave + NW * (i >> 1) : half_nt;
         const int t = i < 2 * NF ? (i & 1) : half_tok;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
@@ -320,7 +337,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
     constexpr int C4 = C / 4;
     if (part) {
 #pragma unroll 4
-        for (int idx = tid; idx < 64 * C4; idx += 256) {
+        for (int idx = tid; idx < 64 * C4; idx += NT) {
             const int row = idx / C4, c = (idx % C4) * 4;
             const int m = tile * 64 + row;
             if (m >= a.M) continue;
@@ -329,15 +346,15 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
     } else {
         // unsplit: the rows are final here.  4 threads per token row (64-byte segments), so the NEXT block's LN1 (optional) is a
         // two-shuffle reduction over the finished row and leaves as split planes from the same registers: no LayerNorm launch
-        const int row = tid >> 2, sub = tid & 3;
+        const int row = tid / TPR, sub = tid % TPR;
         const int m = tile * 64 + row;
         const bool live = m < a.M;
-        constexpr int NV = C / 16;
+        constexpr int NV = C / (4 * TPR), CS = 4 * TPR;
         float4 v[NV];
         float sum = 0.f;
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
-            const int c = 16 * i + 4 * sub;
+            const int c = CS * i + 4 * sub;
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (live) {
                 float4 t = *reinterpret_cast<const float4*>(otile + row * ORS + c);
@@ -353,6 +370,7 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
         if (a.ln_hi[s]) {
             sum += __shfl_xor(sum, 1);
             sum += __shfl_xor(sum, 2);
+            if constexpr (TPR == 8) sum += __shfl_xor(sum, 4);
             const float mean = sum * (1.0f / C);
             float q = 0.f;
 #pragma unroll
@@ -362,11 +380,12 @@ __global__ __launch_bounds__(256) void mlp_fused_kernel(MlpArgs a) {
             }
             q += __shfl_xor(q, 1);
             q += __shfl_xor(q, 2);
+            if constexpr (TPR == 8) q += __shfl_xor(q, 4);
             const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
             if (live) {
 #pragma unroll
                 for (int i = 0; i < NV; ++i) {
-                    const int c = 16 * i + 4 * sub;
+                    const int c = CS * i + 4 * sub;
                     const float4 g = *reinterpret_cast<const float4*>(a.ln_gamma[s] + c), b = *reinterpret_cast<const float4*>(a.ln_beta[s] + c);
                     const float n[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
                                         (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
@@ -474,19 +493,21 @@ __global__ __launch_bounds__(256) void mlp_reduce_ln_kernel(MlpArgs a, int C, in
     }
 }
 
-template <int C>
+template <int C, int NW>
 int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
-    constexpr int lds = (64 * (C + 8) + 64 * (128 + 8)) * 2 * 2;
+    // A image + H image (NW = 4) or A image with H laid over it + gamma / beta (NW = 8)
+    constexpr int lds = NW == 8 ? 64 * (C + 8) * 2 * 2 + 2 * C * 4 : (64 * (C + 8) + 64 * (32 * NW + 8)) * 2 * 2;
+    if (NW == 8 && a.nchunks != 1) return fail(SWF_ERR_UNSUPPORTED, "mlp_fused: the 8-wave kernel takes one hidden chunk per workgroup");
     static std::once_flag once;   // > 64 KB of dynamic LDS needs the attribute once per kernel (thread-safe)
     static hipError_t attr_err = hipSuccess;
     if (lds > 65536) {
         std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         });
         if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "mlp_fused: cannot raise the dynamic LDS limit to %d B", lds);
     }
     dim3 grid((a.M + 63) / 64, a.splits, nstream);
-    hipLaunchKernelGGL((mlp_fused_kernel<C>), grid, dim3(256), lds, stream, a);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW>), grid, dim3(64 * NW), lds, stream, a);
     SWF_TRY(check_launch("mlp_fused"));
     MlpArgs ra = a;   // the reduce kernels' residual is the row that entered LN2
     for (int s = 0; s < nstream; ++s)
@@ -507,6 +528,12 @@ int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
 
 }  // namespace
 
+// 8 waves on one 256-wide hidden chunk per workgroup (C = 384; SWF_MLP8=0: the 4-wave kernel, tools only)
+static bool mlp_wide(int C, int HID) {
+    static const bool off = [] { const char* e = std::getenv("SWF_MLP8"); return e && e[0] == '0'; }();
+    return !off && C == 384 && HID % 256 == 0;
+}
+
 bool mlp_fused_supported(int C, int HID) {
     return (C == 128 || C == 192 || C == 256 || C == 384) && HID > 0 && HID % 128 == 0 && (int64_t)C * HID < (1 << 30);
 }
@@ -514,6 +541,7 @@ bool mlp_fused_supported(int C, int HID) {
 // hidden splits as a function of the layer shape alone: about two 128-wide chunks per workgroup
 int mlp_fused_splits(int C, int HID) {
     static const int forced = [] { const char* e = std::getenv("SWF_MLP_SPLITS"); return e ? atoi(e) : 0; }();   // tools: tuning override
+    if (mlp_wide(C, HID)) return HID / 256;
     if (forced > 0 && (HID / 128) % forced == 0) return forced;
     const int chunks = HID / 128;
     // measured at B=16 256x256 (us, kernel + reduce): C=192 hid 768: S=1 33, S=2 23+6, S=3 32+7; C=384 hid 1536: S=2 56, S=4 38+5,
@@ -541,7 +569,8 @@ int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream) {
     }
     a.M = d.M; a.HID = d.HID;
     a.splits = mlp_fused_splits(d.C, d.HID);
-    a.nchunks = d.HID / 128 / a.splits;
+    const bool wide = mlp_wide(d.C, d.HID);
+    a.nchunks = d.HID / (wide ? 256 : 128) / a.splits;
     a.scratch = d.scratch;
     if (d.ln_hi[0])
         for (int s = 0; s < nstream; ++s) {
@@ -551,10 +580,10 @@ int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream) {
     if (a.splits > 1 && (!d.scratch || (int64_t)nstream * a.splits * d.M * d.C > d.scratch_floats))
         return fail(SWF_ERR_WORKSPACE, "mlp_fused: scratch too small for %d hidden splits", a.splits);
     switch (d.C) {
-        case 128: return launch_c<128>(a, nstream, stream);
-        case 192: return launch_c<192>(a, nstream, stream);
-        case 256: return launch_c<256>(a, nstream, stream);
-        case 384: return launch_c<384>(a, nstream, stream);
+        case 128: return launch_c<128, 4>(a, nstream, stream);
+        case 192: return launch_c<192, 4>(a, nstream, stream);
+        case 256: return launch_c<256, 4>(a, nstream, stream);
+        case 384: return wide ? launch_c<384, 8>(a, nstream, stream) : launch_c<384, 4>(a, nstream, stream);
     }
     return fail(SWF_ERR_UNSUPPORTED, "mlp_fused: C=%d", d.C);
 }

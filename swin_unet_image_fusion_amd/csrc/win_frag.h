@@ -77,8 +77,8 @@ __device__ __forceinline__ T* uniform_ptr(T* p) {
 
 
 // Copy the fp32 vector sections of the two streams' packed images (n4 16-byte groups each) into LDS with every load of a thread
-// issued before its first store.  (The obvious strided loop "lvec[i] = src[i]" runs one dependent global round trip per iteration:
-// at 1 248 floats per stream that was 20 us of a 48-us launch — stamped with wall_clock64, DESIGN.md.)
+// issued before its first store (the obvious strided loop "lvec[i] = src[i]" runs one dependent global round trip per iteration;
+// worth 0.7 us of a 48-us level-1 launch).
 template <int N4, int NTHREADS>
 __device__ __forceinline__ void fill_vectors(float* lvec, const char* vec0, const char* vec1, int tid) {
     constexpr int PER = (2 * N4 + NTHREADS - 1) / NTHREADS;

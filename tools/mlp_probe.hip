@@ -4,7 +4,9 @@
 // wall_clock64() ticks at 100 MHz (10 ns).
 #include "../swin_unet_image_fusion_amd/csrc/kernels_mlp.hip"
 
+#include <algorithm>
 #include <cstdio>
+#include <cstdlib>
 #include <vector>
 
 using namespace swf;
@@ -33,9 +35,31 @@ int main() {
         for (int it = 0; it < 3; ++it)
             if (launch_mlp_fused(d, 2, st) != SWF_OK) { printf("launch failed: %s\n", swf_last_error_string()); return 1; }
         CK(hipStreamSynchronize(st));
+        hipEvent_t e0, e1;
+        CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
+        CK(hipEventRecord(e0, st));
+        for (int it = 0; it < 10; ++it) launch_mlp_fused(d, 2, st);
+        CK(hipEventRecord(e1, st));
+        CK(hipStreamSynchronize(st));
+        float ms = 0.f;
+        CK(hipEventElapsedTime(&ms, e0, e1));
         unsigned long long h[64];
         CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(swf_mlp_probe), sizeof(h)));
-        const int nch = sh.HID / 128 / S;
+        {   // every workgroup's entry / exit, relative to the first entry (last launch)
+            static unsigned long long wg[2 * 4096];
+            CK(hipMemcpyFromSymbol(wg, HIP_SYMBOL(swf_mlp_wg), sizeof(wg)));
+            const int nwg = ((sh.M + 63) / 64) * S * 2;
+            std::vector<double> en, ex;
+            unsigned long long t0 = ~0ull;
+            for (int i = 0; i < nwg; ++i) t0 = std::min(t0, wg[2 * i]);
+            for (int i = 0; i < nwg; ++i) { en.push_back((wg[2 * i] - t0) * 0.01); ex.push_back((wg[2 * i + 1] - t0) * 0.01); }
+            std::sort(en.begin(), en.end()); std::sort(ex.begin(), ex.end());
+            printf("%s: %d workgroups, launch+reduce pair %.1f us by events; entry median %.2f max %.2f | exit min %.2f median %.2f max %.2f\n", sh.name, nwg,
+                   ms * 100.f, en[nwg / 2], en[nwg - 1], ex[0], ex[nwg / 2], ex[nwg - 1]);
+        }
+        const char* e8 = getenv("SWF_MLP8");
+        const bool wide = sh.C == 384 && sh.HID % 256 == 0 && !(e8 && e8[0] == '0');   // as mlp_wide() in kernels_mlp.hip
+        const int nch = sh.HID / (wide ? 256 : 128) / S;
         printf("%s C=%d hid=%d S=%d chunks/WG=%d (us from kernel entry of WG %d): LN done %.2f", sh.name, sh.C, sh.HID, S, nch, SWF_MLP_PROBE, (h[1] - h[0]) * 0.01);
         for (int c = 0; c < nch && c < 8; ++c)
             printf(" | ch%d fc1 %.2f H %.2f bar %.2f fc2 %.2f", c, (h[2 + 4 * c] - h[0]) * 0.01, (h[3 + 4 * c] - h[0]) * 0.01, (h[4 + 4 * c] - h[0]) * 0.01, (h[5 + 4 * c] - h[0]) * 0.01);
