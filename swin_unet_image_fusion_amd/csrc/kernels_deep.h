@@ -25,7 +25,7 @@ struct SpGemmBatch {
     float qscale = 1.0f;               // SP_EPI_QKV16
 };
 // SP_EPI_QKV16: the operands of the attention core in their final formats, written to o_hi [M][N] (16-bit elements):
-// problem p % 3 == 0 -> bf16((acc + bias) * batch.qscale) (Q, scale = d^-0.5 * log2 e), == 1 -> bf16 (K), == 2 -> fp16 (V)
+// problem p % 3 == 0 -> fp16((acc + bias) * batch.qscale) (Q, scale = d^-0.5 * log2 e), == 1 -> fp16 (K), == 2 -> fp16 (V)
 enum { SP_EPI_F32 = 0, SP_EPI_ELU_SPLIT = 1, SP_EPI_QKV16 = 2 };
 
 bool gemm_sp_supported(int N, int K);
@@ -38,7 +38,7 @@ int launch_split_planes(const float* src, bf16_raw* hi, bf16_raw* lo, int64_t n,
 
 // bytes of the pre-split weight image of ONE stream of one block:
 // planes hi|lo of [Wq | Wk | Wv | Wproj | Wfc1 | Wfc2], each in nn.Linear layout, then (when the fused MLP kernel
-// covers the shape) fragment-major copies of Wfc1 and Wfc2
+// covers the shape) fragment-major copies of Wfc1 and Wfc2 (and of Wproj where kernels_attnproj.hip covers the shape)
 size_t deep_block_packed_bytes(const swf_block_desc& d);
 bool deep_block_supported(const swf_block_desc& d);
 int pack_deep_block(const swf_block_desc& d, const swf_block_stream_params& p, void* packed, hipStream_t stream);
@@ -48,6 +48,7 @@ struct DeepWeights {   // views into one packed image
     // fc1 / fc2 again in MFMA-fragment-major order for the fused MLP kernel (kernels_mlp.hip), or nullptr:
     // block (row tile rt of 32 rows, k16 step ks) = 64 lanes x 8 bf16, lane = 32*hf + r holds row 32rt+r, k = 16ks+8hf..+7
     const bf16_raw *w1f_hi, *w1f_lo, *w2f_hi, *w2f_lo;
+    const bf16_raw *pf_hi, *pf_lo;   // Wproj in the same fragment-major order for the attention + projection kernel (kernels_attnproj.hip), or nullptr
     const void* qa;   // section of the fused Q/K/V + attention kernel (kernels_qkvattn.h), or nullptr
 };
 DeepWeights deep_block_views(const swf_block_desc& d, const void* packed);

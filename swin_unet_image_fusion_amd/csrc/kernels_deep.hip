@@ -10,6 +10,7 @@
 // Global loads of step k+1 are issued before the MFMAs of step k and stored to the other stage after them:
 // one barrier per step.
 #include "kernels_deep.h"
+#include "kernels_attnproj.h"
 #include "kernels_window.h"
 #include "kernels_mlp.h"
 #include "kernels_qkvattn.h"
@@ -353,13 +354,14 @@ int launch_split_planes(const float* src, bf16_raw* hi, bf16_raw* lo, int64_t n,
 
 // ---- packed weight image of one stream of one block ----------------------------------------------------
 namespace {
-struct DeepSizes { int64_t qkv, proj, w1, w2, fm, total; };
+struct DeepSizes { int64_t qkv, proj, w1, w2, fm, pfm, total; };
 DeepSizes deep_sizes(const swf_block_desc& d) {
     const int64_t C = d.attn.channels, HD = (int64_t)d.attn.heads * d.attn.head_dim, hid = d.hidden;
     DeepSizes s;
     s.qkv = HD * C; s.proj = C * HD; s.w1 = hid * C; s.w2 = C * hid;
     s.fm = mlp_fused_supported((int)C, (int)hid) ? s.w1 + s.w2 : 0;   // fragment-major copies of fc1 | fc2
-    s.total = 3 * s.qkv + s.proj + s.w1 + s.w2 + s.fm;
+    s.pfm = attnproj_supported(d) && HD == C ? s.proj : 0;              // fragment-major copy of Wproj (kernels_attnproj.hip)
+    s.total = 3 * s.qkv + s.proj + s.w1 + s.w2 + s.fm + s.pfm;
     return s;
 }
 }  // namespace
@@ -393,8 +395,10 @@ DeepWeights deep_block_views(const swf_block_desc& d, const void* packed) {
     w.w1f_hi = w.w1f_lo = w.w2f_hi = w.w2f_lo = nullptr;
     if (s.fm) {
         w.w1f_hi = hi + o; w.w1f_lo = lo + o; o += s.w1;
-        w.w2f_hi = hi + o; w.w2f_lo = lo + o;
+        w.w2f_hi = hi + o; w.w2f_lo = lo + o; o += s.w2;
     }
+    w.pf_hi = w.pf_lo = nullptr;
+    if (s.pfm) { w.pf_hi = hi + o; w.pf_lo = lo + o; o += s.pfm; }
     w.qa = qkvattn_packed_bytes(d) ? static_cast<const char*>(packed) + deep_planes_bytes(d) : nullptr;
     return w;
 }
@@ -423,6 +427,14 @@ int pack_deep_block(const swf_block_desc& d, const swf_block_stream_params& p, v
             SWF_TRY(check_launch("pack_fragmajor"));
             o += n2;
         }
+    }
+    if (s.pfm) {
+        const int C = d.attn.channels;
+        dim3 grid((unsigned)std::min<int64_t>(cdiv64(s.pfm, 256), 4096));
+        hipLaunchKernelGGL(pack_fragmajor_kernel, grid, dim3(256), 0, stream, p.attn.proj.weight, reinterpret_cast<bf16*>(hi + o),
+                           reinterpret_cast<bf16*>(lo + o), C, C);
+        SWF_TRY(check_launch("pack_fragmajor(proj)"));
+        o += s.pfm;
     }
     if (qkvattn_packed_bytes(d)) SWF_TRY(pack_qkvattn(d, p, static_cast<char*>(packed) + deep_planes_bytes(d), stream));
     return SWF_OK;

@@ -15,6 +15,7 @@
 #include "kernels_patchrr.h"
 #include "kernels_mlp.h"
 #include "kernels_qkvattn.h"
+#include "kernels_attnproj.h"
 
 namespace swf {
 
@@ -317,7 +318,19 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
     }
     gq.qscale = 1.4426950408889634f / std::sqrt((float)desc->attn.head_dim);   // d^-0.5 (a001:32-34) and exp -> exp2
     if (!fused_attn) SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_QKV16, stream));
-    if (!fused_attn) {
+    // level 4 (C = 384): attention core + output projection + residual in one launch
+    const bool attn_proj = !fused_attn && HD == C && attnproj_supported(*desc) && wv[0].pf_hi && (nstream == 1 || wv[1].pf_hi);
+    if (attn_proj) {
+        AttnProjArgs ap{};
+        for (int s = 0; s < nstream; ++s) {
+            ap.q[s] = qkv[s][0]; ap.k[s] = qkv[s][1]; ap.v[s] = qkv[s][2];
+            ap.wp_hi[s] = wv[s].pf_hi; ap.wp_lo[s] = wv[s].pf_lo; ap.pbias[s] = pp[s]->attn.proj.bias; ap.table[s] = pp[s]->attn.bias_table;
+            ap.res[s] = xin[s]; ap.out[s] = xout[s];
+        }
+        ap.B = B; ap.H = H; ap.W = W; ap.shift = desc->attn.shift;
+        SWF_TRY(launch_attnproj(*desc, ap, nstream, stream));
+    }
+    if (!fused_attn && !attn_proj) {
         const bf16_raw* qq[2] = {qkv[0][0], qkv[1][0]};
         const bf16_raw* kk[2] = {qkv[0][1], qkv[1][1]};
         const bf16_raw* vv[2] = {qkv[0][2], qkv[1][2]};
@@ -333,7 +346,7 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
     gp.scratch = sk; gp.scratch_floats = sk_floats;
     for (int s = 0; s < nstream; ++s)
         gp.p[s] = SpGemmProb{o_hi[s], o_lo[s], wv[s].p_hi, wv[s].p_lo, pp[s]->attn.proj.bias, xin[s], xout[s], nullptr, nullptr};
-    if (!fold_proj) SWF_TRY(launch_gemm_sp(gp, nstream, (int)N, C, HD, C, SP_EPI_F32, stream));
+    if (!fold_proj && !attn_proj) SWF_TRY(launch_gemm_sp(gp, nstream, (int)N, C, HD, C, SP_EPI_F32, stream));
     // MLP half (a004:29-38 around a003:46-50)
     if (fused_mlp) {   // LN2 + fc1 + ELU + fc2 + residual in one launch (+ a fixed-order reduce over the hidden splits)
         MlpFusedDesc md{};
