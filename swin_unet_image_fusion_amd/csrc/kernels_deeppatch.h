@@ -1,0 +1,20 @@
+// Patch layers of the deep levels (fast tier), one launch each (kernels_deeppatch.hip): gather -> conv (bf16x3 MFMA, weights
+// pre-packed fragment-major) -> LayerNorm -> ELU (-> depth-to-space scatter + skip).  Shapes: 2x2 merging with
+// (K, N) = (384, 192), (768, 384) in the encoder and (384, 768), (192, 384) in the decoder; everything else stays on
+// launch_patch_rr / launch_patch_fused / the GEMM path.
+#pragma once
+#include "kernels_patch.h"
+
+namespace swf {
+
+bool deep_patch_supported(int decoder, int Cin, int Cout, int mh, int mw);
+// bytes of the packed conv weight of ONE stream of one layer (0 = shape not covered)
+size_t deep_patch_packed_bytes(int decoder, int Cin, int Cout, int mh, int mw);
+int pack_deep_patch(int decoder, int Cin, int Cout, int mh, int mw, const float* weight, void* dst, hipStream_t stream);
+// The two layers next to the deepest level run conv + bias only, over column slices (deep_patch_raw): the caller passes
+// raw_out[s] = [M][N] fp32 and runs LayerNorm (+ scatter) on it as a second launch.
+bool deep_patch_raw(int decoder, int Cin, int Cout, int mh, int mw);
+// d as for launch_patch_fused (d.w is not read); packed[s]: the stream's image written by pack_deep_patch
+int launch_deep_patch(const PatchFusedDesc& d, const void* const* packed, int nstream, hipStream_t stream, float* const* raw_out = nullptr);
+
+}  // namespace swf

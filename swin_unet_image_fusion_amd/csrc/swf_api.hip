@@ -13,6 +13,7 @@
 #include "kernels_deep.h"
 #include "kernels_patch.h"
 #include "kernels_patchrr.h"
+#include "kernels_deeppatch.h"
 #include "kernels_mlp.h"
 #include "kernels_qkvattn.h"
 #include "kernels_attnproj.h"
@@ -494,7 +495,8 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
     static const bool no_prr = std::getenv("SWF_NO_PATCH_RR") != nullptr;
     const bool use_prr = fast && !no_fused && !no_prr && prr && nstream == 2 && patch_rr_supported(0, Cin, Cout, mh, mw) &&
                          (int64_t)B * H * W * Cin < (int64_t(1) << 31);
-    if (use_prr || (fast && !no_fused && patch_fused_supported(K, Cout))) {   // one launch: gather -> conv -> LN -> ELU
+    const bool use_dp = fast && !no_fused && !use_prr && prr && deep_patch_supported(0, Cin, Cout, mh, mw) && (int64_t)B * H * W * Cin < (int64_t(1) << 31);
+    if (use_prr || use_dp || (fast && !no_fused && patch_fused_supported(K, Cout))) {   // one launch: gather -> conv -> LN -> ELU
         PatchFusedDesc d{};
         for (int s = 0; s < nstream; ++s) {
             d.in[s] = in[s]; d.out[s] = out[s]; d.skip[s] = nullptr;
@@ -503,6 +505,16 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
         d.decoder = 0; d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.mh = mh; d.mw = mw; d.Hm = Hm; d.Wm = Wm; d.Ho = Ho; d.Wo = Wo;
         d.K = K; d.N = Cout; d.Cout = Cout; d.M = N;
         if (use_prr) return launch_patch_rr(d, prr, nstream, stream);
+        if (use_dp && deep_patch_raw(0, Cin, Cout, mh, mw)) {   // conv over column slices, then LayerNorm + ELU as a second launch
+            Carver wz(workspace, workspace_bytes);
+            float* zr[2] = {nullptr, nullptr};
+            LnBatch lz{};
+            for (int s = 0; s < nstream; ++s) { zr[s] = wz.floats(N * Cout); lz.p[s] = LnProb{zr[s], out[s], p[s]->ln.gamma, p[s]->ln.beta}; }
+            if (!wz.ok()) return fail(SWF_ERR_WORKSPACE, "patch-merge workspace too small (need %zu B)", wz.used);
+            SWF_TRY(launch_deep_patch(d, prr, nstream, stream, zr));
+            return launch_layernorm(lz, nstream, N, Cout, 1, stream);
+        }
+        if (use_dp) return launch_deep_patch(d, prr, nstream, stream);
         return launch_patch_fused(d, nstream, stream);
     }
     Carver ws(workspace, workspace_bytes);
@@ -540,7 +552,8 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
     static const bool no_prr = std::getenv("SWF_NO_PATCH_RR") != nullptr;
     const bool use_prr = fast && !no_fused && !no_prr && prr && nstream == 2 && patch_rr_supported(1, Cin, Cout, mh, mw) &&
                          (int64_t)B * Hp * Wp * Cin < (int64_t(1) << 31);
-    if (use_prr || (fast && !no_fused && patch_fused_supported(Cin, Kz))) {   // one launch: crop -> conv -> LN -> scatter -> ELU (+ skip)
+    const bool use_dp = fast && !no_fused && !use_prr && prr && deep_patch_supported(1, Cin, Cout, mh, mw) && (int64_t)B * Hp * Wp * Cin < (int64_t(1) << 31);
+    if (use_prr || use_dp || (fast && !no_fused && patch_fused_supported(Cin, Kz))) {   // one launch: crop -> conv -> LN -> scatter -> ELU (+ skip)
         PatchFusedDesc d{};
         for (int s = 0; s < nstream; ++s) {
             d.in[s] = in[s]; d.out[s] = out[s]; d.skip[s] = skip ? skip[s] : nullptr;
@@ -549,7 +562,25 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
         d.decoder = 1; d.B = B; d.H = Hp; d.W = Wp; d.Cin = Cin; d.mh = mh; d.mw = mw; d.Hm = Hm; d.Wm = Wm; d.Ho = Hout; d.Wo = Wout;
         d.K = Cin; d.N = Kz; d.Cout = Cout; d.M = N;
         if (use_prr) return launch_patch_rr(d, prr, nstream, stream);
-        return launch_patch_fused(d, nstream, stream);
+        if (use_dp && deep_patch_raw(1, Cin, Cout, mh, mw)) {   // conv over column slices, then LayerNorm + scatter + ELU (+ skip)
+            Carver wz(workspace, workspace_bytes);
+            float* zr[2] = {nullptr, nullptr};
+            LnBatch lz{};
+            PtrPair sz{};
+            for (int s = 0; s < nstream; ++s) {
+                zr[s] = wz.floats(N * Kz);
+                lz.p[s] = LnProb{zr[s], nullptr, p[s]->ln.gamma, p[s]->ln.beta};
+                sz.in[s] = zr[s]; sz.out[s] = out[s]; sz.aux[s] = skip ? skip[s] : nullptr;
+            }
+            if (!wz.ok()) return fail(SWF_ERR_WORKSPACE, "patch-unmerge workspace too small (need %zu B)", wz.used);
+            if (ln_unmerge_scatter_supported(lz, sz, nstream, Cout, mh, mw)) {
+                SWF_TRY(launch_deep_patch(d, prr, nstream, stream, zr));
+                return launch_ln_unmerge_scatter(lz, sz, nstream, B, Hm, Wm, Cout, mh, mw, Hout, Wout, stream);
+            }
+        } else if (use_dp) {
+            return launch_deep_patch(d, prr, nstream, stream);
+        }
+        if (!use_dp) return launch_patch_fused(d, nstream, stream);
     }
     Carver ws(workspace, workspace_bytes);
     float* cr[2] = {nullptr, nullptr};
@@ -805,7 +836,8 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
 struct PackedPlan {
     size_t enc[SWF_MAX_LEVELS], dec[SWF_MAX_LEVELS], total;
     bool enc_on[SWF_MAX_LEVELS], dec_on[SWF_MAX_LEVELS];
-    // patch layers (register-resident kernel): two per-stream images of penc_b / pdec_b bytes each, 0 = layer not covered
+    // patch layers (register-resident kernel, or the deep-level kernel where that one does not cover the shape): two per-stream
+    // images of penc_b / pdec_b bytes each, 0 = layer not covered
     size_t penc[SWF_MAX_LEVELS], pdec[SWF_MAX_LEVELS], penc_b[SWF_MAX_LEVELS], pdec_b[SWF_MAX_LEVELS];
 };
 static PackedPlan packed_plan(const swf_model_desc* d) {
@@ -825,11 +857,13 @@ static PackedPlan packed_plan(const swf_model_desc* d) {
     }
     for (int s = 0; s < d->levels; ++s) {
         p.penc_b[s] = patch_rr_packed_bytes(0, d->in_dims[s], d->out_dims[s], d->merge_h, d->merge_w);
+        if (!p.penc_b[s]) p.penc_b[s] = deep_patch_packed_bytes(0, d->in_dims[s], d->out_dims[s], d->merge_h, d->merge_w);
         p.penc[s] = off; off += 2 * p.penc_b[s];
     }
     for (int j = 0; j < d->levels; ++j) {
         const int lvl = d->levels - 1 - j;
         p.pdec_b[j] = patch_rr_packed_bytes(1, d->out_dims[lvl], d->in_dims[lvl], d->merge_h, d->merge_w);
+        if (!p.pdec_b[j]) p.pdec_b[j] = deep_patch_packed_bytes(1, d->out_dims[lvl], d->in_dims[lvl], d->merge_h, d->merge_w);
         p.pdec[j] = off; off += 2 * p.pdec_b[j];
     }
     p.total = off;
@@ -1122,13 +1156,21 @@ int swf_model_pack_weights(const swf_model_desc* desc, const float* arena, void*
         for (int st = 0; st < 2; ++st) {
             if (plan.penc_b[k]) {
                 const PatchOff& o = L->enc_patch[k][st];
-                SWF_TRY(pack_patch_rr(0, desc->in_dims[k], desc->out_dims[k], desc->merge_h, desc->merge_w, arena + o.w, arena + o.b, arena + o.g,
-                                      arena + o.bt, base + plan.penc[k] + st * plan.penc_b[k], stream));
+                if (patch_rr_packed_bytes(0, desc->in_dims[k], desc->out_dims[k], desc->merge_h, desc->merge_w))
+                    SWF_TRY(pack_patch_rr(0, desc->in_dims[k], desc->out_dims[k], desc->merge_h, desc->merge_w, arena + o.w, arena + o.b, arena + o.g,
+                                          arena + o.bt, base + plan.penc[k] + st * plan.penc_b[k], stream));
+                else
+                    SWF_TRY(pack_deep_patch(0, desc->in_dims[k], desc->out_dims[k], desc->merge_h, desc->merge_w, arena + o.w,
+                                            base + plan.penc[k] + st * plan.penc_b[k], stream));
             }
             if (plan.pdec_b[k]) {
                 const PatchOff& o = L->dec_patch[k][st];
-                SWF_TRY(pack_patch_rr(1, desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, arena + o.w, arena + o.b,
-                                      arena + o.g, arena + o.bt, base + plan.pdec[k] + st * plan.pdec_b[k], stream));
+                if (patch_rr_packed_bytes(1, desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w))
+                    SWF_TRY(pack_patch_rr(1, desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, arena + o.w, arena + o.b,
+                                          arena + o.g, arena + o.bt, base + plan.pdec[k] + st * plan.pdec_b[k], stream));
+                else
+                    SWF_TRY(pack_deep_patch(1, desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, arena + o.w,
+                                            base + plan.pdec[k] + st * plan.pdec_b[k], stream));
             }
         }
     }
