@@ -48,6 +48,7 @@ struct DeepWeights {   // views into one packed image
     // fc1 / fc2 again in MFMA-fragment-major order for the fused MLP kernel (kernels_mlp.hip), or nullptr:
     // block (row tile rt of 32 rows, k16 step ks) = 64 lanes x 8 bf16, lane = 32*hf + r holds row 32rt+r, k = 16ks+8hf..+7
     const bf16_raw *w1f_hi, *w1f_lo, *w2f_hi, *w2f_lo;
+    const bf16_raw *qkvf_hi, *qkvf_lo;   // Wq | Wk | Wv stacked, fragment-major (launch_deep_qkv, kernels_deeppatch.h), or nullptr
     const bf16_raw *pf_hi, *pf_lo;   // Wproj in the same fragment-major order for the attention + projection kernel (kernels_attnproj.hip), or nullptr
     const void* qa;   // section of the fused Q/K/V + attention kernel (kernels_qkvattn.h), or nullptr
 };

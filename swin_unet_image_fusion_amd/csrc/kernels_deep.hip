@@ -11,6 +11,7 @@
 // one barrier per step.
 #include "kernels_deep.h"
 #include "kernels_attnproj.h"
+#include "kernels_deeppatch.h"
 #include "kernels_window.h"
 #include "kernels_mlp.h"
 #include "kernels_qkvattn.h"
@@ -354,14 +355,15 @@ int launch_split_planes(const float* src, bf16_raw* hi, bf16_raw* lo, int64_t n,
 
 // ---- packed weight image of one stream of one block ----------------------------------------------------
 namespace {
-struct DeepSizes { int64_t qkv, proj, w1, w2, fm, pfm, total; };
+struct DeepSizes { int64_t qkv, proj, w1, w2, fm, pfm, qfm, total; };
 DeepSizes deep_sizes(const swf_block_desc& d) {
     const int64_t C = d.attn.channels, HD = (int64_t)d.attn.heads * d.attn.head_dim, hid = d.hidden;
     DeepSizes s;
     s.qkv = HD * C; s.proj = C * HD; s.w1 = hid * C; s.w2 = C * hid;
     s.fm = mlp_fused_supported((int)C, (int)hid) ? s.w1 + s.w2 : 0;   // fragment-major copies of fc1 | fc2
     s.pfm = attnproj_supported(d) && HD == C ? s.proj : 0;              // fragment-major copy of Wproj (kernels_attnproj.hip)
-    s.total = 3 * s.qkv + s.proj + s.w1 + s.w2 + s.fm + s.pfm;
+    s.qfm = deep_qkv_supported(d) ? 3 * s.qkv : 0;                        // fragment-major Wq | Wk | Wv (kernels_deeppatch.hip)
+    s.total = 3 * s.qkv + s.proj + s.w1 + s.w2 + s.fm + s.pfm + s.qfm;
     return s;
 }
 }  // namespace
@@ -399,6 +401,8 @@ DeepWeights deep_block_views(const swf_block_desc& d, const void* packed) {
     }
     w.pf_hi = w.pf_lo = nullptr;
     if (s.pfm) { w.pf_hi = hi + o; w.pf_lo = lo + o; o += s.pfm; }
+    w.qkvf_hi = w.qkvf_lo = nullptr;
+    if (s.qfm) { w.qkvf_hi = hi + o; w.qkvf_lo = lo + o; o += s.qfm; }
     w.qa = qkvattn_packed_bytes(d) ? static_cast<const char*>(packed) + deep_planes_bytes(d) : nullptr;
     return w;
 }
@@ -435,6 +439,17 @@ int pack_deep_block(const swf_block_desc& d, const swf_block_stream_params& p, v
                            reinterpret_cast<bf16*>(lo + o), C, C);
         SWF_TRY(check_launch("pack_fragmajor(proj)"));
         o += s.pfm;
+    }
+    if (s.qfm) {   // the three images one after the other = the fragment-major image of the stacked matrix
+        const int C = d.attn.channels, HD = d.attn.heads * d.attn.head_dim;
+        const float* qsrc[3] = {p.attn.q.weight, p.attn.k.weight, p.attn.v.weight};
+        for (int i = 0; i < 3; ++i) {
+            dim3 grid((unsigned)std::min<int64_t>(cdiv64(s.qkv, 256), 4096));
+            hipLaunchKernelGGL(pack_fragmajor_kernel, grid, dim3(256), 0, stream, qsrc[i], reinterpret_cast<bf16*>(hi + o),
+                               reinterpret_cast<bf16*>(lo + o), HD, C);
+            SWF_TRY(check_launch("pack_fragmajor(qkv)"));
+            o += s.qkv;
+        }
     }
     if (qkvattn_packed_bytes(d)) SWF_TRY(pack_qkvattn(d, p, static_cast<char*>(packed) + deep_planes_bytes(d), stream));
     return SWF_OK;

@@ -17,4 +17,16 @@ bool deep_patch_raw(int decoder, int Cin, int Cout, int mh, int mw);
 // d as for launch_patch_fused (d.w is not read); packed[s]: the stream's image written by pack_deep_patch
 int launch_deep_patch(const PatchFusedDesc& d, const void* const* packed, int nstream, hipStream_t stream, float* const* raw_out = nullptr);
 
+// Q/K/V projections of a level-4 block (C = heads * head_dim = 384) on the same kernel: LayerNorm planes [M][384] in, the attention
+// core's fp16 operands out (Q pre-scaled by qscale).  Replaces launch_gemm_sp(..., SP_EPI_QKV16).
+struct DeepQkvArgs {
+    const unsigned short* xn_hi[2]; const unsigned short* xn_lo[2];   // LayerNorm planes (bf16 hi / lo) of each stream
+    const unsigned short* w_hi[2]; const unsigned short* w_lo[2];     // Wq | Wk | Wv stacked [1152][384], fragment-major (DeepWeights::qkvf_*)
+    const float* bias[2][3];                                          // q, k, v bias or nullptr
+    unsigned short* out[2][3];                                        // fp16 [M][384] each
+    float qscale; int cross, M;                                       // cross: K and V of stream s read stream 1 - s
+};
+bool deep_qkv_supported(const swf_block_desc& d);
+int launch_deep_qkv(const DeepQkvArgs& q, int nstream, hipStream_t stream);
+
 }  // namespace swf

@@ -28,6 +28,8 @@ struct DpArgs {
     const bf16* w_hi[2]; const bf16* w_lo[2];
     const float* bias[2]; const float* gamma[2]; const float* beta[2];
     int B, H, W, Hm, Wm, Ho, Wo, M;
+    // Q/K/V mode (DEC == 2): LayerNorm planes in, fp16 operands of the attention core out
+    const bf16* xh[2]; const bf16* xl[2]; const float* qb[2][3]; f16* qo[2][3]; float qscale; int cross;
 };
 
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * n - 2 - i; }   // bottom / right only
@@ -46,7 +48,11 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
     // it owns columns [N z, N z + N) of NTOT (z = blockIdx.z) and writes conv + bias to a.out as rows [M][NTOT]; LayerNorm runs as
     // a second launch.  The two layers next to the deepest level take this form: 1 024 tokens per stream are 16-32 whole-row
     // workgroups, each MFMA-bound for 11 us on an eighth of the chip.
-    constexpr bool RAW = NTOT != N;
+    // DEC == 2 (Q/K/V projections of a level-4 block, raw form): the rows are the LayerNorm planes [M][K] (already split bf16), the
+    // NTOT = 3 K weight rows are Wq | Wk | Wv stacked, and the epilogue writes (acc + bias) [* d^-0.5 log2 e for Q] as fp16 — the
+    // operand formats of attn_proj_kernel (SP_EPI_QKV16 of the GEMM this replaces).  K and V of a cross block read the other stream.
+    constexpr bool RAW = NTOT != N, IS_DEC = DEC == 1, IS_QKV = DEC == 2;
+    static_assert(!IS_QKV || (RAW && NTOT == 3 * K && K % N == 0 && K <= 384), "Q/K/V mode");
     constexpr int NT = 64 * NW, MR = 32 * MT, TPR = NT / MR;           // threads, token rows per workgroup, threads per row
     constexpr int KC = K > 384 ? 384 : K, NKC = K / KC, KS = KC / 16;   // columns staged at once, passes, k16 steps per pass
     constexpr int T = N / 32, NF = T / NW, R = T % NW;                  // 32-column tiles; whole tiles per wave; left-over tiles
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
     constexpr int D = NFRAG % 8 == 0 ? 8 : 6;                           // ring depth
     static_assert(NFRAG % D == 0, "ring depth must divide the fragment count");
     constexpr int LDA = KC + 8, ORS = N + 4;                            // row strides: odd multiples of 16 B
-    constexpr int CIN = DEC ? K : K / 4, COUT = DEC ? NTOT / 4 : NTOT;  // channels per input / output pixel (2x2 merging)
+    constexpr int CIN = IS_DEC ? K : K / 4, COUT = IS_DEC ? NTOT / 4 : NTOT;  // channels per input / output pixel (2x2 merging)
     constexpr size_t img_bytes = size_t(2) * MR * LDA * 2, out_bytes = size_t(MR) * ORS * 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16* a_hi = reinterpret_cast<bf16*>(smem);
@@ -86,18 +92,37 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
     // ---- source rows of this workgroup: thread (row, sub) covers float4 columns sub, sub + TPR, ... of the staged K chunk ----
     const int row = tid / TPR, sub = tid % TPR;
     const int m = min(tile * MR + row, a.M - 1);   // rows past M are computed on a clamped copy and never stored
-    int rb, ry, rx;                                 // batch index and position of the row's token in its (merged) map
-    if (DEC) { rx = m % a.Wm; const int t = m / a.Wm; ry = t % a.Hm; rb = t / a.Hm; }
-    else { rx = m % a.Wo; const int t = m / a.Wo; ry = t % a.Ho; rb = t / a.Ho; }
+    int rb = 0, ry = 0, rx = 0;                     // batch index and position of the row's token in its (merged) map
+    if (IS_DEC) { rx = m % a.Wm; const int t = m / a.Wm; ry = t % a.Hm; rb = t / a.Hm; }
+    else if (!IS_QKV) { rx = m % a.Wo; const int t = m / a.Wo; ry = t % a.Ho; rb = t / a.Ho; }
+    const int which = IS_QKV ? (32 * ct0) / K : 0;   // 0 = Q, 1 = K, 2 = V
     constexpr int NV = KC / (4 * TPR);
     static_assert(KC % (4 * TPR) == 0, "row chunks must divide over the row's threads");
     auto stage = [&](int kc) {   // K chunk kc of the rows -> split-bf16 LDS image
+        if constexpr (IS_QKV) {   // the planes are copied as they are: 16-byte chunks of 8 bf16
+            constexpr int NQ = KC / (8 * TPR);
+            const int ss = (which != 0 && a.cross) ? 1 - s : s;
+            const bf16* ph = a.xh[ss] + (size_t)m * K;
+            const bf16* pl = a.xl[ss] + (size_t)m * K;
+            u32x4 vh[NQ], vl[NQ];
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                vh[i] = *reinterpret_cast<const u32x4*>(ph + 8 * (sub + TPR * i));
+                vl[i] = *reinterpret_cast<const u32x4*>(pl + 8 * (sub + TPR * i));
+            }
+#pragma unroll
+            for (int i = 0; i < NQ; ++i) {
+                *reinterpret_cast<u32x4*>(a_hi + row * LDA + 8 * (sub + TPR * i)) = vh[i];
+                *reinterpret_cast<u32x4*>(a_lo + row * LDA + 8 * (sub + TPR * i)) = vl[i];
+            }
+            return;
+        }
         float4 v[NV];
 #pragma unroll
         for (int i = 0; i < NV; ++i) {
             const int col = kc * KC + 4 * (sub + TPR * i);   // column of the conv input row
             const float* src;
-            if (DEC) {
+            if (IS_DEC) {
                 src = a.in[s] + ((size_t)(rb * a.H + ry) * a.W + rx) * CIN + col;   // crop: only Hm x Wm of the H x W map is read
             } else {
                 const int pq = col / CIN, c = col - pq * CIN, ph = pq >> 1, pw = pq & 1;   // 2x2 merging: (ph, pw, channel) order
@@ -122,8 +147,8 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
     // decoder: the skip rows this thread adds at the very end are requested now (cold encoder activations: ~2 us from HBM)
     constexpr int NO = N / (4 * TPR);
     static_assert(N % (4 * TPR) == 0, "output row chunks must divide over the row's threads");
-    f32x4 sk[DEC && !RAW ? NO : 1];
-    if constexpr (DEC && !RAW) {
+    f32x4 sk[IS_DEC && !RAW ? NO : 1];
+    if constexpr (IS_DEC && !RAW) {
 #pragma unroll
         for (int i = 0; i < NO; ++i) {
             const int c = 4 * (sub + TPR * i), p = c / COUT, cc = c - p * COUT;
@@ -228,12 +253,30 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
     for (int i = 0; i < NO; ++i) {
         const int c = 4 * (sub + TPR * i);
         v[i] = *reinterpret_cast<const f32x4*>(otile + row * ORS + c);
-        if (a.bias[s]) v[i] += *reinterpret_cast<const f32x4*>(a.bias[s] + 32 * ct0 + c);
+        if constexpr (IS_QKV) {
+            if (a.qb[s][which]) v[i] += *reinterpret_cast<const f32x4*>(a.qb[s][which] + 32 * ct0 - which * K + c);
+        } else {
+            if (a.bias[s]) v[i] += *reinterpret_cast<const f32x4*>(a.bias[s] + 32 * ct0 + c);
+        }
         if constexpr (!RAW) {
             gm[i] = *reinterpret_cast<const f32x4*>(a.gamma[s] + c);
             bt[i] = *reinterpret_cast<const f32x4*>(a.beta[s] + c);
         }
         sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    if constexpr (IS_QKV) {
+        if (live) {
+            const float sc = which == 0 ? a.qscale : 1.0f;
+            f16* dst = a.qo[s][which] + (size_t)m * K + 32 * ct0 - which * K;
+            typedef f16 f16x4 __attribute__((ext_vector_type(4)));
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const f16x4 h = {(f16)(v[i][0] * sc), (f16)(v[i][1] * sc), (f16)(v[i][2] * sc), (f16)(v[i][3] * sc)};
+                *reinterpret_cast<f16x4*>(dst + 4 * (sub + TPR * i)) = h;
+            }
+        }
+        DP_STAMP(10);
+        return;
     }
     if constexpr (RAW) {
         if (live) {
@@ -262,7 +305,7 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
         f32x4 o;
 #pragma unroll
         for (int j = 0; j < 4; ++j) o[j] = elu_fast((v[i][j] - mean) * rstd * gm[i][j] + bt[i][j]);
-        if constexpr (DEC) {
+        if constexpr (IS_DEC) {
             const int p = c / COUT, cc = c - p * COUT;   // Cout % 4 == 0: a chunk never straddles sub-pixels
             const int y = 2 * ry + (p >> 1), xo = 2 * rx + (p & 1);
             if (y < a.Ho && xo < a.Wo) {
@@ -315,6 +358,27 @@ int launch_t(const DpArgs& a, int nstream, hipStream_t stream) {
 }
 
 }  // namespace
+
+bool deep_qkv_supported(const swf_block_desc& d) {
+    static const bool off = std::getenv("SWF_NO_DEEP_QKV") != nullptr;   // A/B switch (tools)
+    return !off && d.precision == SWF_PREC_FAST && d.attn.channels == 384 && d.attn.heads * d.attn.head_dim == 384;
+}
+
+int launch_deep_qkv(const DeepQkvArgs& q, int nstream, hipStream_t stream) {
+    if (q.M <= 0 || q.M > INT32_MAX / 2048) return fail(SWF_ERR_UNSUPPORTED, "deep_qkv: token count");
+    DpArgs a{};
+    for (int s = 0; s < nstream; ++s) {
+        if (!q.xn_hi[s] || !q.xn_lo[s] || !q.w_hi[s] || !q.w_lo[s]) return fail(SWF_ERR_NULL, "deep_qkv: NULL operand (stream %d)", s);
+        a.xh[s] = reinterpret_cast<const bf16*>(q.xn_hi[s]); a.xl[s] = reinterpret_cast<const bf16*>(q.xn_lo[s]);
+        a.w_hi[s] = reinterpret_cast<const bf16*>(q.w_hi[s]); a.w_lo[s] = reinterpret_cast<const bf16*>(q.w_lo[s]);
+        for (int i = 0; i < 3; ++i) {
+            if (!q.out[s][i]) return fail(SWF_ERR_NULL, "deep_qkv: NULL output (stream %d)", s);
+            a.qb[s][i] = q.bias[s][i]; a.qo[s][i] = reinterpret_cast<f16*>(q.out[s][i]);
+        }
+    }
+    a.M = q.M; a.qscale = q.qscale; a.cross = q.cross && nstream == 2;
+    return launch_t<384, 192, 2, 4, 2, 1152>(a, nstream, stream);
+}
 
 bool deep_patch_supported(int decoder, int Cin, int Cout, int mh, int mw) { return shape_index(decoder, Cin, Cout, mh, mw) >= 0; }
 bool deep_patch_raw(int decoder, int Cin, int Cout, int mh, int mw) {

@@ -318,7 +318,18 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         }
     }
     gq.qscale = 1.4426950408889634f / std::sqrt((float)desc->attn.head_dim);   // d^-0.5 (a001:32-34) and exp -> exp2
-    if (!fused_attn) SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_QKV16, stream));
+    const bool deep_qkv = !fused_attn && HD == C && deep_qkv_supported(*desc) && wv[0].qkvf_hi && (nstream == 1 || wv[1].qkvf_hi);
+    if (deep_qkv) {   // level 4: the three projections of both streams in one launch of the rows-times-fragment-major-weights kernel
+        DeepQkvArgs dq{};
+        for (int s = 0; s < nstream; ++s) {
+            dq.xn_hi[s] = xn_hi[s]; dq.xn_lo[s] = xn_lo[s]; dq.w_hi[s] = wv[s].qkvf_hi; dq.w_lo[s] = wv[s].qkvf_lo;
+            dq.bias[s][0] = pp[s]->attn.q.bias; dq.bias[s][1] = pp[s]->attn.k.bias; dq.bias[s][2] = pp[s]->attn.v.bias;
+            for (int i = 0; i < 3; ++i) dq.out[s][i] = qkv[s][i];
+        }
+        dq.qscale = gq.qscale; dq.cross = cross; dq.M = (int)N;
+        SWF_TRY(launch_deep_qkv(dq, nstream, stream));
+    }
+    if (!fused_attn && !deep_qkv) SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_QKV16, stream));
     // level 4 (C = 384): attention core + output projection + residual in one launch
     const bool attn_proj = !fused_attn && HD == C && attnproj_supported(*desc) && wv[0].pf_hi && (nstream == 1 || wv[1].pf_hi);
     if (attn_proj) {
