@@ -12,6 +12,7 @@
 #include "kernels_win96.h"
 
 #include <algorithm>
+#include <cstdlib>
 
 #include "win_frag.h"
 
@@ -38,6 +39,8 @@ struct G96 {
     static constexpr size_t p_total = p_bias + size_t(2) * 2 * 16 * 64 * 4;
     // LDS: K images [stream 2][key tile 2][vch tile 4][k-step 2] x 1 KB, V^T images [stream 2][vch tile 4][pv-step 4] x 1 KB, vectors
     static constexpr size_t l_k = 0, l_v = 32 * 1024, l_vec = 64 * 1024, l_total = l_vec + size_t(2) * VSTREAM * 4;
+    // window96x8_kernel: the same images, the split-K exchange buffers [wave 8][12][lane 64] x 16 B laid over them, vectors behind
+    static constexpr size_t l_vec8 = 96 * 1024, l_total8 = l_vec8 + size_t(2) * VSTREAM * 4;
     // 16x16 windows (window96w16_kernel): bias tiles by key-tile / query-tile distance, fp32 [distance 15][reg/4 4][lane 64][4];
     // LDS of ONE stream: K images [key tile 8][vch tile 4][k-step 2] x 1 KB, V^T images [vch tile 4][pv-step 16] x 1 KB, vectors
     static constexpr size_t p_total16 = p_bias + size_t(15) * 16 * 64 * 4;
@@ -92,13 +95,15 @@ __device__ __forceinline__ void layernorm96(const f32x16 (&x)[3], const float* v
 // the wave's Q fragments (k-step = head within the tile); bias: relative-position bias of (stream, query block) with -inf where the
 // shift mask applies.  Returns the four O^T tiles: registers 8*sp .. 8*sp + 7 of tile T = head 2T + sp (lane half 1: register
 // 8*sp + 4 is the softmax denominator).
-__device__ __forceinline__ void attention96(const u32x4* ksrc, const u32x4* vsrc, const u32x4 (&qf)[4][2], const f32x16 (&bias)[2],
-                                            bool half1, f32x16 (&o)[4]) {
+// (NH < 8: the NH heads whose images start at ksrc / vsrc — window96x8_kernel passes pointers advanced to its first tile.)
+template <int NH = 8>
+__device__ __forceinline__ void attention96(const u32x4* ksrc, const u32x4* vsrc, const u32x4 (&qf)[NH / 2][2], const f32x16 (&bias)[2],
+                                            bool half1, f32x16 (&o)[NH / 2]) {
     const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int T = 0; T < 4; ++T) o[T] = zero16;
+    for (int T = 0; T < NH / 2; ++T) o[T] = zero16;
 #pragma unroll
-    for (int h = 0; h < 8; ++h) {
+    for (int h = 0; h < NH; ++h) {
         const int T = h >> 1, sp = h & 1;
         const u32x4 ka0 = ksrc[((0 * 4 + T) * 2 + sp) * 64], ka1 = ksrc[((1 * 4 + T) * 2 + sp) * 64];
         u32x4 qm = qf[T][sp];
@@ -399,6 +404,320 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
         for (int s2 = 0; s2 < 2; ++s2)
             for (int l = l0 + tid; l < l1; l += 256) acc ^= *reinterpret_cast<const unsigned*>(args.warm[s2] + (size_t)l * 128);
         if (acc == 0x9e3779b9u && args.B < 0) args.out[0][0] = 0.f;   // never true: keeps the loads alive
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// The same block with EIGHT waves per window: wave = (stream w >> 2, 32-token half (w >> 1) & 1, feature half fh = w & 1).  At
+// B=16 256x256 the level has 256 windows for 256 CUs: window96_kernel then runs ONE wave per SIMD, a chain of small latencies it
+// cannot overlap (45 us against 10 us of MFMAs).  Here the two waves of a token half split the OUTPUT FEATURES: heads 4 fh .. 4 fh + 3
+// of Q / K / V and the attention, the k-steps of those heads in the projection (split-K), hidden tiles fh NT1/2 .. in fc1 and
+// their k-steps in fc2 (split-K) — each weight fragment still crosses the memory pipe once per token half, a wave carries half the
+// MFMAs, and two waves per SIMD cover each other's round trips.  LayerNorm runs in both waves (each holds the full rows); the
+// two split-K partial sums meet through LDS (buffers laid over the K / V images once the attention has read them), added in the
+// same order in both waves (a + b == b + a), so both continue with identical rows.  Used when the launch has at most one window
+// per CU; results differ from window96_kernel's in the last bits only (summation order of the two split-K halves).
+#ifdef W96_PROBE   // diagnostic build (tools/w96_probe.py): wall-clock stamps (10 ns) of workgroup 0, wave 0 of window96x8_kernel
+__device__ unsigned long long w96_probe[16];
+#define W96_STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) w96_probe[i] = wall_clock64(); } while (0)
+#else
+#define W96_STAMP(i) do { } while (0)
+#endif
+
+template <int HID, int WS>
+__global__ __launch_bounds__(512) void window96x8_kernel(Win96Args args) {
+    using G = G96<HID>;
+    static_assert(WS == 7 || WS == 8, "window side");
+    static_assert(G::NT1 % 2 == 0, "hidden tiles split over the two feature halves");
+    constexpr int NTH = G::NT1 / 2;
+    extern __shared__ __attribute__((aligned(16))) char smem96[];
+    u32x4* kimg = reinterpret_cast<u32x4*>(smem96 + G::l_k);   // [stream][key tile][vch tile][k-step][lane]
+    u32x4* vimg = reinterpret_cast<u32x4*>(smem96 + G::l_v);   // [stream][vch tile][pv-step][lane]
+    f32x4* xch = reinterpret_cast<f32x4*>(smem96);             // [wave 8][group 12][lane 64]: split-K partials, laid over the images
+    float* lvec = reinterpret_cast<float*>(smem96 + G::l_vec8);
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int ws = wave >> 2, qb = (wave >> 1) & 1, fh = wave & 1, r = lane & 31, hf = lane >> 5;
+    const int H = args.H, W = args.W, nwx = W / WS, nwy = H / WS, npi = nwx * nwy;
+    const int nwin = args.B * npi;
+    const int sh = args.shift ? WS / 2 : 0;
+    const int kvs = args.cross ? 1 - ws : ws;
+
+    const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
+    const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
+    const int act_bytes = args.B * H * W * 96 * 4;
+    const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(args.in[ws])), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, act_bytes, 0x00020000);
+    const unsigned loff = (unsigned)lane * 16u;
+    auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };
+    auto WK = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, loff, f * 1024, 0)); };
+    const float* vec = lvec + ws * G::VSTREAM + hf * G::VHF;
+    const float* veck = lvec + kvs * G::VSTREAM + hf * G::VHF;
+    const float* vecv = lvec + kvs * G::VSTREAM + 2 * G::VHF;
+    const bool half1 = hf != 0;
+    const bool col_masked = half1 != (((r >> 2) & 1) != 0);
+    const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    // the wave's split-K partial [3 tiles] -> its exchange slot / + the partner's
+    auto put = [&](const f32x16 (&p)[3]) {
+#pragma unroll
+        for (int a = 0; a < 12; ++a)
+            xch[(wave * 12 + a) * 64 + lane] = f32x4{p[a >> 2][4 * (a & 3)], p[a >> 2][4 * (a & 3) + 1], p[a >> 2][4 * (a & 3) + 2], p[a >> 2][4 * (a & 3) + 3]};
+    };
+    auto add_partner = [&](f32x16 (&p)[3]) {
+#pragma unroll
+        for (int a = 0; a < 12; ++a) {
+            const f32x4 o = xch[((wave ^ 1) * 12 + a) * 64 + lane];
+            p[a >> 2][4 * (a & 3)] += o[0]; p[a >> 2][4 * (a & 3) + 1] += o[1]; p[a >> 2][4 * (a & 3) + 2] += o[2]; p[a >> 2][4 * (a & 3) + 3] += o[3];
+        }
+    };
+
+    W96_STAMP(0);
+    for (int win = blockIdx.x; win < nwin; win += gridDim.x) {
+        W96_STAMP(11 + (win != (int)blockIdx.x));
+        SWF_WF_FENCE();
+        const int b = win / npi, wrem = win - b * npi;
+        const int wy = wrem / nwx, wx = wrem - wy * nwx;
+        const int ty = 4 * qb + (r >> 3), tx = r & 7;
+        int oy = wy * WS + ty + sh, ox = wx * WS + tx + sh;
+        oy = oy >= H ? oy - H : oy;
+        ox = ox >= W ? ox - W : ox;
+        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 96 + 4 * hf) * 4) : 0x80000000u;
+        auto load_rows = [&](f32x16 (&x)[3]) {
+#pragma unroll
+            for (int a = 0; a < 12; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(irs, tokoff, 32 * a, 0));
+                x[a >> 2][4 * (a & 3)] = v.x; x[a >> 2][4 * (a & 3) + 1] = v.y; x[a >> 2][4 * (a & 3) + 2] = v.z; x[a >> 2][4 * (a & 3) + 3] = v.w;
+            }
+        };
+
+        // ---- LN1 (both feature halves), then Q / K / V of virtual-channel tiles 2 fh and 2 fh + 1 = heads 4 fh .. 4 fh + 3 ----
+        u32x4 qf[2][2];
+        {
+            // 12 half phases: (Q, K, V) x 2 tiles x two halves of the six k-steps, as window96_kernel, but with the fragments of
+            // PD half phases in flight: the registers are there (the residual rows are not live yet), and with one set ahead every
+            // half phase (9 MFMAs) waited most of an L2 round trip
+            constexpr int PD = 4;
+            u32x4 wq[PD][6];
+            auto req = [&](int hp, u32x4 (&dst)[6]) {
+                const int m = hp >> 2, f0 = G::F_QKV + ((m * 4 + ((hp >> 1) & 1)) * 6 + 3 * (hp & 1)) * 2 + fh * 24;
+#pragma unroll
+                for (int i = 0; i < 6; ++i) dst[i] = m == 0 ? WF(f0 + i) : WK(f0 + i);
+            };
+            req(0, wq[0]);
+            u32x4 xh[6], xl[6];
+            {
+                f32x16 x[3];
+                load_rows(x);
+#pragma unroll
+                for (int p = 1; p < PD - 1; ++p) req(p, wq[p]);
+                if (win == (int)blockIdx.x) {
+                    static_assert(G::VSTREAM % 4 == 0 && G::p_vec % 16 == 0, "vector sections move as 16-byte groups");
+                    fill_vectors<G::VSTREAM / 4, 512>(lvec, args.packed[0] + G::p_vec, args.packed[1] + G::p_vec, tid);
+                    __syncthreads();
+                }
+                layernorm96(x, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+            }
+            W96_STAMP(1);
+            f32x16 acc = zero16;
+#pragma unroll
+            for (int hp = 0; hp < 12; ++hp) {
+                const int m = hp >> 2, Tl = (hp >> 1) & 1, half = hp & 1, T = 2 * fh + Tl;
+                SWF_WF_FENCE();
+                if (hp + PD - 1 < 12) req(hp + PD - 1, wq[(hp + PD - 1) % PD]);
+                SWF_WF_FENCE();
+                const u32x4 (&w)[6] = wq[hp % PD];
+                if (half == 0) acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 3; ++s) {
+                    const int ks = 3 * half + s;
+                    acc = m < 2 ? mma3(w[2 * s], w[2 * s + 1], xh[ks], xl[ks], acc)
+                                : mma3(xh[ks], xl[ks], w[2 * s], w[2 * s + 1], acc);
+                }
+                if (half == 1) {
+                    float t[16];
+                    if (m < 2) {
+                        const float* bsrc = m == 0 ? vec + G::V_BQ : veck + G::V_BK;
+#pragma unroll
+                        for (int g = 0; g < 4; ++g) {
+                            const float4 bb = *reinterpret_cast<const float4*>(bsrc + 16 * T + 4 * g);
+                            t[4 * g] = acc[4 * g] + bb.x; t[4 * g + 1] = acc[4 * g + 1] + bb.y; t[4 * g + 2] = acc[4 * g + 2] + bb.z; t[4 * g + 3] = acc[4 * g + 3] + bb.w;
+                        }
+                        if (m == 0) {
+                            qf[Tl][0] = pack8_f16(t);
+                            qf[Tl][1] = pack8_f16(t + 8);
+                        } else {
+                            if (Tl == 0 && win != (int)blockIdx.x) __syncthreads();   // the window before has read the images and the exchange buffers
+                            u32x4* kdst = kimg + (((kvs * 2 + qb) * 4 + T) * 2) * 64 + lane;
+                            kdst[0] = pack8_f16(t);
+                            kdst[64] = pack8_f16(t + 8);
+                        }
+                    } else {
+                        const float bv = vecv[32 * T + r];
+#pragma unroll
+                        for (int i = 0; i < 16; ++i) t[i] = acc[i] + bv;
+                        u32x4* vdst = vimg + ((kvs * 4 + T) * 4 + 2 * qb) * 64 + lane;
+                        vdst[0] = pack8_f16(t);
+                        vdst[64] = pack8_f16(t + 8);
+                    }
+                }
+            }
+        }
+        W96_STAMP(2);
+        f32x16 bias[2];
+#pragma unroll
+        for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+            for (int a = 0; a < 4; ++a) {
+                const f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, (int)G::p_bias + ((qb * 2 + kt) * 4 + a) * 1024, 0));
+                bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
+            }
+        __syncthreads();   // K / V^T images of both streams complete
+        W96_STAMP(3);
+
+        // ---- attention of the wave's 32 queries, its 4 heads ----
+        f32x16 o[2];
+        {
+            const bool rowv = args.shift && wy == nwy - 1, colv = args.shift && wx == nwx - 1;
+            const u32x4* ksrc = kimg + (ws * 16 + fh * 4) * 64 + lane;   // + fh * 2 tiles of 2 k-steps
+            const u32x4* vsrc = vimg + (ws * 16 + fh * 8) * 64 + lane;   // + fh * 2 tiles of 4 pv-steps
+            if (rowv || colv) {
+                const float pen0 = ((rowv && qb == 1) || (colv && col_masked)) ? -INFINITY : 0.f;
+                const float pen1 = ((rowv && qb == 0) || (colv && col_masked)) ? -INFINITY : 0.f;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) { bias[0][i] += pen0; bias[1][i] += pen1; }
+            }
+            attention96<4>(ksrc, vsrc, qf, bias, half1, o);
+        }
+        W96_STAMP(4);
+
+        // ---- normalise, output projection over the own heads' k-steps (split-K): feature half 0 accumulates onto the residual
+        //      rows, half 1 from zero; the two sums meet through LDS ----
+        f32x16 res[3];
+        {
+            u32x4 wp[4][6];   // all four k-steps of this wave: [out tile][hi, lo]
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int To = 0; To < 3; ++To) {
+                    wp[ks][2 * To] = WF(G::F_P + (To * 8 + ks) * 2 + fh * 8);
+                    wp[ks][2 * To + 1] = WF(G::F_P + (To * 8 + ks) * 2 + 1 + fh * 8);
+                }
+            SWF_WF_FENCE();
+            if (fh == 0) load_rows(res);
+            else { res[0] = zero16; res[1] = zero16; res[2] = zero16; }
+            SWF_WF_FENCE();
+            u32x4 oh[4], ol[4];   // k-step = head
+#pragma unroll
+            for (int h = 0; h < 4; ++h) {
+                const int T = h >> 1, sp = h & 1;
+                float lo_, den;
+                halves(o[T][8 * sp + 4], lo_, den);
+                const float inv = __builtin_amdgcn_rcpf(den);
+                float t[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) t[j] = o[T][8 * sp + j] * inv;
+                split8(t, oh[h], ol[h]);
+            }
+#pragma unroll
+            for (int ks = 0; ks < 4; ++ks)
+#pragma unroll
+                for (int To = 0; To < 3; ++To) res[To] = mma3(wp[ks][2 * To], wp[ks][2 * To + 1], oh[ks], ol[ks], res[To]);
+        }
+        W96_STAMP(5);
+        __syncthreads();   // every wave has left the K / V^T images: the exchange buffers take their place
+        put(res);
+        __syncthreads();
+        add_partner(res);   // (rows + heads 0-3) + heads 4-7 in both waves
+        W96_STAMP(6);
+
+        // ---- LN2 (both halves), MLP over the own hidden tiles: fc1 tile -> ELU -> split -> two k-steps of fc2 (split-K partial) ----
+        {
+            // Every fragment of a hidden tile (12 of fc1, 12 of fc2) has a register slot that is refilled with the NEXT tile's
+            // fragment right after its MFMAs: a full tile of lead for every load (requesting fc2's at the tile start and fc1's
+            // after the fc1 MFMAs left half a tile).  Past the last tile the refill re-reads the last tile (dead loads, no branch).
+            u32x4 w1[12], w2[3][2][2];
+            auto f1 = [&](int tI, int i) { return WF(G::F_W1 + tI * 12 + i + fh * (NTH * 12)); };
+            auto f2 = [&](int tI, int To, int s2, int hl) { return WF(G::F_W2 + (To * G::KU + 2 * tI + s2) * 2 + hl + fh * (NTH * 4)); };
+#pragma unroll
+            for (int i = 0; i < 12; ++i) w1[i] = f1(0, i);   // in flight during LN2
+            SWF_WF_FENCE();
+            u32x4 xh[6], xl[6];
+            layernorm96(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+            if (fh != 0) { res[0] = zero16; res[1] = zero16; res[2] = zero16; }   // half 1 carries its fc2 partial alone
+            W96_STAMP(7);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int To = 0; To < 3; ++To) { w2[To][s2][0] = f2(0, To, s2, 0); w2[To][s2][1] = f2(0, To, s2, 1); }
+            SWF_WF_FENCE();
+#pragma unroll 1
+            for (int tI = 0; tI < NTH; ++tI) {
+                const int tn = tI + 1 < NTH ? tI + 1 : tI;
+                f32x16 acc = zero16;
+#pragma unroll
+                for (int s = 0; s < 6; ++s) {
+                    acc = mma3(w1[2 * s], w1[2 * s + 1], xh[s], xl[s], acc);
+                    SWF_WF_FENCE();
+                    w1[2 * s] = f1(tn, 2 * s); w1[2 * s + 1] = f1(tn, 2 * s + 1);
+                    SWF_WF_FENCE();
+                }
+                float e[16];
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const float4 b1 = *reinterpret_cast<const float4*>(vec + G::V_B1 + 16 * (fh * NTH + tI) + 4 * g);
+                    const float bb[4] = {b1.x, b1.y, b1.z, b1.w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const float u = acc[4 * g + j] + bb[j];
+                        const float L = __builtin_fmaf(__builtin_amdgcn_exp2f(u), kLog2e, -kLog2e);
+                        e[4 * g + j] = __builtin_amdgcn_fmed3f(u, L, 0.f);
+                    }
+                }
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2) {
+                    u32x4 hh, hl;
+                    split8(e + 8 * s2, hh, hl);
+#pragma unroll
+                    for (int To = 0; To < 3; ++To) {
+                        res[To] = mma3(w2[To][s2][0], w2[To][s2][1], hh, hl, res[To]);
+                        SWF_WF_FENCE();
+                        w2[To][s2][0] = f2(tn, To, s2, 0); w2[To][s2][1] = f2(tn, To, s2, 1);
+                        SWF_WF_FENCE();
+                    }
+                }
+            }
+        }
+        W96_STAMP(8);
+        __syncthreads();   // the projection's sums have been read
+        put(res);
+        __syncthreads();
+        add_partner(res);   // (x1 + hidden tiles of half 0) + hidden tiles of half 1 in both waves
+#pragma unroll
+        for (int a = 0; a < 12; ++a) {
+            const float4 b2 = *reinterpret_cast<const float4*>(vec + G::V_B2 + 4 * a);
+            res[a >> 2][4 * (a & 3)] += b2.x; res[a >> 2][4 * (a & 3) + 1] += b2.y; res[a >> 2][4 * (a & 3) + 2] += b2.z; res[a >> 2][4 * (a & 3) + 3] += b2.w;
+        }
+
+        W96_STAMP(9);
+        // ---- store: each feature half writes six of the lane's twelve 16-byte groups ----
+#pragma unroll
+        for (int a = 0; a < 12; ++a) {
+            if ((a >= 6) != (fh != 0)) continue;
+            const f32x4 v = {res[a >> 2][4 * (a & 3)], res[a >> 2][4 * (a & 3) + 1], res[a >> 2][4 * (a & 3) + 2], res[a >> 2][4 * (a & 3) + 3]};
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), ors, tokoff, 32 * a, 0);
+        }
+    }
+
+    W96_STAMP(10);
+    if (args.warm[0]) {
+        const int nsl = max(1, (int)gridDim.x / 8), sl = ((int)blockIdx.x / 8) % nsl;
+        const int lines = (args.warm_bytes + 127) / 128;
+        const int per = (lines + nsl - 1) / nsl, l0 = sl * per, l1 = min(lines, l0 + per);
+        unsigned acc = 0;
+        for (int s2 = 0; s2 < 2; ++s2)
+            for (int l = l0 + tid; l < l1; l += 512) acc ^= *reinterpret_cast<const unsigned*>(args.warm[s2] + (size_t)l * 128);
+        if (acc == 0x9e3779b9u && args.B < 0) args.out[0][0] = 0.f;
     }
 }
 
@@ -859,6 +1178,15 @@ static int launch96_t(const Win96Args& a, int grid, hipStream_t stream) {
     return check_launch("window96");
 }
 
+template <int HID, int WS>
+static int launch96x8_t(const Win96Args& a, int grid, hipStream_t stream) {
+    constexpr int lds = (int)G96<HID>::l_total8;
+    static hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&window96x8_kernel<HID, WS>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window96x8): %s", hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((window96x8_kernel<HID, WS>), dim3(grid), dim3(512), lds, stream, a);
+    return check_launch("window96x8");
+}
+
 int launch_win96(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,
                  float* x_out, float* y_out, int B, int H, int W, hipStream_t stream, const void* next_packed_x,
                  const void* next_packed_y, size_t next_bytes) {
@@ -884,9 +1212,23 @@ int launch_win96(const swf_block_desc& d, const void* packed_x, const void* pack
         else hipLaunchKernelGGL((window96w16_kernel<192>), dim3(gx, 2), dim3(256), G96<192>::l_total16, stream, a);
         return check_launch("window96w16");
     }
+    static const bool no_x8 = [] { const char* e = std::getenv("SWF_WIN96X8"); return e && e[0] == '0'; }();   // A/B switch (tools)
+    // Maps of up to 16 windows (32 x 32 tokens: B=16 256x256 has 256 windows for 256 CUs) take eight waves per window
+    // (window96x8_kernel).  The rule looks at the map, never at the batch: batch shards stay bit-identical.
+    if (!no_x8 && (H / wsd) * (W / wsd) <= 16) {
+        const int gx = std::min(nwin, num_cus96());
+        if (wsd == 8) return d.hidden == 384 ? launch96x8_t<384, 8>(a, gx, stream) : launch96x8_t<192, 8>(a, gx, stream);
+        return d.hidden == 384 ? launch96x8_t<384, 7>(a, gx, stream) : launch96x8_t<192, 7>(a, gx, stream);
+    }
     const int grid = std::min(nwin, 2 * num_cus96());
     if (wsd == 8) return d.hidden == 384 ? launch96_t<384, 8>(a, grid, stream) : launch96_t<192, 8>(a, grid, stream);
     return d.hidden == 384 ? launch96_t<384, 7>(a, grid, stream) : launch96_t<192, 7>(a, grid, stream);
 }
 
 }  // namespace swf
+
+#ifdef W96_PROBE
+extern "C" int swf_w96_probe_read(unsigned long long* out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(swf::w96_probe), 16 * sizeof(unsigned long long)) == hipSuccess ? 0 : 1;
+}
+#endif
