@@ -416,7 +416,9 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
 // their k-steps in fc2 (split-K) — each weight fragment still crosses the memory pipe once per token half, a wave carries half the
 // MFMAs, and two waves per SIMD cover each other's round trips.  LayerNorm runs in both waves (each holds the full rows); the
 // two split-K partial sums meet through LDS (buffers laid over the K / V images once the attention has read them), added in the
-// same order in both waves (a + b == b + a), so both continue with identical rows.  Used when the launch has at most one window
+// same order in both waves (a + b == b + a), so both continue with identical rows.  (Measured next to it: four waves that each
+// carry BOTH token halves of a feature half, so that a window pulls half the fragment bytes — 44.5 / 37.1 us against 41.6 / 35.1
+// here and 45.5 / 37.3 for window96_kernel: the fragment stream is not the bound either.)  Used when the launch has at most one window
 // per CU; results differ from window96_kernel's in the last bits only (summation order of the two split-K halves).
 #ifdef W96_PROBE   // diagnostic build (tools/w96_probe.py): wall-clock stamps (10 ns) of workgroup 0, wave 0 of window96x8_kernel
 __device__ unsigned long long w96_probe[16];
@@ -720,6 +722,7 @@ __global__ __launch_bounds__(512) void window96x8_kernel(Win96Args args) {
         if (acc == 0x9e3779b9u && args.B < 0) args.out[0][0] = 0.f;
     }
 }
+
 
 // ---------------------------------------------------------------------------------------------------------------
 // 16x16 windows at C = 96 (BASELINE config 5, level 2): one workgroup = (window, stream) as in window48w16_kernel
