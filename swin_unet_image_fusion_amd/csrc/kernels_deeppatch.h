@@ -14,8 +14,16 @@ int pack_deep_patch(int decoder, int Cin, int Cout, int mh, int mw, const float*
 // The two layers next to the deepest level run conv + bias only, over column slices (deep_patch_raw): the caller passes
 // raw_out[s] = [M][N] fp32 and runs LayerNorm (+ scatter) on it as a second launch.
 bool deep_patch_raw(int decoder, int Cin, int Cout, int mh, int mw);
+// Optional extras of the whole-row (non-raw) layers.  Encoder: LayerNorm of the finished rows with ln_gamma / ln_beta (the next
+// block's LN1) written as split-bf16 planes [M][N] (all four pointers of a stream, or none).  Decoder: packed weights to touch at
+// the end of the launch (L2 warm-up for the block that runs next), warm_bytes per stream.
+struct DeepPatchExtra {
+    const float* ln_gamma[2]; const float* ln_beta[2]; unsigned short* ln_hi[2]; unsigned short* ln_lo[2];
+    const void* warm[2]; size_t warm_bytes;
+};
 // d as for launch_patch_fused (d.w is not read); packed[s]: the stream's image written by pack_deep_patch
-int launch_deep_patch(const PatchFusedDesc& d, const void* const* packed, int nstream, hipStream_t stream, float* const* raw_out = nullptr);
+int launch_deep_patch(const PatchFusedDesc& d, const void* const* packed, int nstream, hipStream_t stream, float* const* raw_out = nullptr,
+                      const DeepPatchExtra* extra = nullptr);
 
 // Q/K/V projections of a level-4 block (C = heads * head_dim = 384) on the same kernel: LayerNorm planes [M][384] in, the attention
 // core's fp16 operands out (Q pre-scaled by qscale).  Replaces launch_gemm_sp(..., SP_EPI_QKV16).

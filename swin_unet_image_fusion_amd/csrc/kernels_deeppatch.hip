@@ -30,6 +30,10 @@ struct DpArgs {
     int B, H, W, Hm, Wm, Ho, Wo, M;
     // Q/K/V mode (DEC == 2): LayerNorm planes in, fp16 operands of the attention core out
     const bf16* xh[2]; const bf16* xl[2]; const float* qb[2][3]; f16* qo[2][3]; float qscale; int cross;
+    // encoder, whole-row form: LayerNorm of the finished rows with these parameters (the next block's LN1) as split-bf16 planes [M][N], or nullptr
+    const float* ln_g[2]; const float* ln_b[2]; bf16* ln_hi[2]; bf16* ln_lo[2];
+    // decoder, whole-row form: packed weights of the block that runs next, touched at the end (per-XCD L2 warm-up, kernels_window.hip), or nullptr
+    const char* warm[2]; int warm_bytes;
 };
 
 __device__ __forceinline__ int reflect_idx(int i, int n) { return i < n ? i : 2 * n - 2 - i; }   // bottom / right only
@@ -298,7 +302,7 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
 #pragma unroll
     for (int o = 1; o < TPR; o <<= 1) q += __shfl_xor(q, o);
     const float rstd = 1.0f / sqrtf(q * (1.0f / N) + 1e-5f);
-    if (!live) return;
+    if (live) {
 #pragma unroll
     for (int i = 0; i < NO; ++i) {
         const int c = 4 * (sub + TPR * i);
@@ -314,6 +318,53 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
             }
         } else {
             *reinterpret_cast<f32x4*>(a.out[s] + (size_t)m * N + c) = o;
+            v[i] = o;
+        }
+    }
+    if constexpr (!IS_DEC) {
+        if (a.ln_hi[s]) {   // the next block's LN1 over the finished row (same threads, same shuffles), written as planes
+            float s2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NO; ++i) s2 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) s2 += __shfl_xor(s2, o);
+            const float mean2 = s2 * (1.0f / N);
+            float q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const float d0 = v[i][0] - mean2, d1 = v[i][1] - mean2, d2 = v[i][2] - mean2, d3 = v[i][3] - mean2;
+                q2 += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+#pragma unroll
+            for (int o = 1; o < TPR; o <<= 1) q2 += __shfl_xor(q2, o);
+            const float rstd2 = 1.0f / sqrtf(q2 * (1.0f / N) + 1e-5f);
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const int c = 4 * (sub + TPR * i);
+                const f32x4 g = *reinterpret_cast<const f32x4*>(a.ln_g[s] + c), bb = *reinterpret_cast<const f32x4*>(a.ln_b[s] + c);
+                bf16x4 h, l;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const float n = (v[i][j] - mean2) * rstd2 * g[j] + bb[j];
+                    h[j] = (bf16)n;
+                    l[j] = (bf16)(n - (float)h[j]);
+                }
+                *reinterpret_cast<bf16x4*>(a.ln_hi[s] + (size_t)m * N + c) = h;
+                *reinterpret_cast<bf16x4*>(a.ln_lo[s] + (size_t)m * N + c) = l;
+            }
+        }
+    }
+    }
+    if constexpr (IS_DEC && !RAW) {
+        if (a.warm[0]) {   // blocks L, L + 8, ... share an XCD: together they touch the whole image (speed only)
+            const int nblk = (int)(gridDim.x * gridDim.y), L = (int)(blockIdx.x + gridDim.x * blockIdx.y);
+            const int nsl = max(1, nblk / 8), sl = (L / 8) % nsl;
+            const int lines = (a.warm_bytes + 127) / 128, per = (lines + nsl - 1) / nsl, l0 = sl * per, l1 = min(lines, l0 + per);
+            unsigned acc = 0;
+            for (int s2 = 0; s2 < 2; ++s2)
+                if (a.warm[s2])
+                    for (int l = l0 + tid; l < l1; l += NT) acc ^= *reinterpret_cast<const unsigned*>(a.warm[s2] + (size_t)l * 128);
+            if (acc == 0x9e3779b9u && a.M < 0) a.out[0][0] = 0.f;   // never true: keeps the loads alive
         }
     }
     DP_STAMP(10);
@@ -400,7 +451,8 @@ int pack_deep_patch(int decoder, int Cin, int Cout, int mh, int mw, const float*
     return check_launch("pack_deep_patch");
 }
 
-int launch_deep_patch(const PatchFusedDesc& d, const void* const* packed, int nstream, hipStream_t stream, float* const* raw_out) {
+int launch_deep_patch(const PatchFusedDesc& d, const void* const* packed, int nstream, hipStream_t stream, float* const* raw_out,
+                      const DeepPatchExtra* extra) {
     const int i = shape_index(d.decoder, d.Cin, d.Cout, d.mh, d.mw);
     if (i < 0) return fail(SWF_ERR_UNSUPPORTED, "deep_patch: shape not covered");
     if (d.M <= 0 || d.M > INT32_MAX / 1024 || (int64_t)d.B * d.H * d.W * d.Cin > INT32_MAX) return fail(SWF_ERR_UNSUPPORTED, "deep_patch: map too large");
@@ -414,6 +466,16 @@ int launch_deep_patch(const PatchFusedDesc& d, const void* const* packed, int ns
         a.bias[s] = d.bias[s]; a.gamma[s] = d.gamma[s]; a.beta[s] = d.beta[s];
     }
     a.B = d.B; a.H = d.H; a.W = d.W; a.Hm = d.Hm; a.Wm = d.Wm; a.Ho = d.Ho; a.Wo = d.Wo; a.M = (int)d.M;
+    if (extra && !kShapes[i].raw) {
+        for (int s = 0; s < nstream; ++s) {
+            if (!d.decoder && extra->ln_hi[s]) {
+                a.ln_g[s] = extra->ln_gamma[s]; a.ln_b[s] = extra->ln_beta[s];
+                a.ln_hi[s] = reinterpret_cast<bf16*>(extra->ln_hi[s]); a.ln_lo[s] = reinterpret_cast<bf16*>(extra->ln_lo[s]);
+            }
+            if (d.decoder) a.warm[s] = static_cast<const char*>(extra->warm[s]);
+        }
+        a.warm_bytes = (int)extra->warm_bytes;
+    }
     switch (i) {
         case 0: return launch_t<384, 192, 2, 4, 0, 192>(a, nstream, stream);
         case 1: return launch_t<768, 128, 2, 4, 0, 384>(a, nstream, stream);

@@ -223,9 +223,10 @@ static size_t deep_block_ws(const swf_block_desc* d, int nstream, int B, int H, 
     if (!deep_block_supported(*d)) return 0;
     const int64_t N = (int64_t)B * H * W, C = d->attn.channels, HD = (int64_t)d->attn.heads * d->attn.head_dim, hid = d->hidden;
     size_t t = 0;
+    for (int s = 0; s < nstream; ++s) t += carve_bytes({N * C / 2, N * C / 2});   // LN1 planes first (deep_ln1_planes)
     for (int s = 0; s < nstream; ++s) {
         t += carve_bytes({(int64_t)deep_block_packed_bytes(*d) / 4});
-        t += carve_bytes({N * C / 2, N * C / 2, N * HD / 2, N * HD / 2, N * HD / 2, N * HD / 2, N * HD / 2, N * hid / 2, N * hid / 2});
+        t += carve_bytes({N * HD / 2, N * HD / 2, N * HD / 2, N * HD / 2, N * HD / 2, N * hid / 2, N * hid / 2});
     }
     int64_t sk = std::max((int64_t)gemm_sp_splitk_for((int)HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for((int)hid, SP_EPI_F32));
     if (mlp_fused_supported((int)C, (int)hid)) sk = std::max(sk, (int64_t)mlp_fused_splits((int)C, (int)hid));
@@ -234,6 +235,16 @@ static size_t deep_block_ws(const swf_block_desc* d, int nstream, int B, int H, 
     if (qkvattn_supported(*d) && mlp_fused_supported((int)C, (int)hid) && HD == C)
         for (int s = 0; s < nstream; ++s) t += carve_bytes({N * C, N * C, N * C});
     return t;
+}
+
+// The LN1 planes of a deep-level block sit at the START of its workspace, at offsets that depend on the token count and C only:
+// whoever runs before the block on the same workspace (the previous block's MLP reduce, the previous stage's last block, the
+// patch-merging kernel) can leave them there and say so through `ln1_ready`.
+static void deep_ln1_planes(Carver& ws, int64_t N, int C, int nstream, bf16_raw** hi, bf16_raw** lo) {
+    for (int s = 0; s < nstream; ++s) {
+        hi[s] = reinterpret_cast<bf16_raw*>(ws.floats(N * C / 2));
+        lo[s] = reinterpret_cast<bf16_raw*>(ws.floats(N * C / 2));
+    }
 }
 
 static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
@@ -257,9 +268,9 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
     bf16_raw *xn_hi[2], *xn_lo[2], *o_hi[2], *o_lo[2], *h_hi[2], *h_lo[2];
     bf16_raw* qkv[2][3];   // Q (bf16, pre-scaled), K (bf16), V (fp16): the attention core's operand formats
     void* wbuf[2] = {nullptr, nullptr};
+    deep_ln1_planes(ws, N, C, nstream, xn_hi, xn_lo);
     for (int s = 0; s < nstream; ++s) {
         wbuf[s] = ws.floats((int64_t)deep_block_packed_bytes(*desc) / 4);
-        xn_hi[s] = planes(N * C); xn_lo[s] = planes(N * C);
         for (int i = 0; i < 3; ++i) qkv[s][i] = planes(N * HD);
         o_hi[s] = planes(N * HD); o_lo[s] = planes(N * HD);
         h_hi[s] = planes(N * hid); h_lo[s] = planes(N * hid);
@@ -421,6 +432,7 @@ static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_p
                             const swf_block_stream_params* const* next_p = nullptr, bool* ln1_ready = nullptr) {
     // next_p / ln1_ready: see deep_block_impl; every other path ignores the planes and leaves *ln1_ready false
     if (desc->precision == SWF_PREC_FAST && py && window_block_supported(*desc, B, H, W)) {
+        if (ln1_ready) *ln1_ready = false;
         const bool prepacked = prepacked_x && prepacked_y;   // model path: weights were packed once (swf_model_pack_weights)
         const size_t pb = window_block_packed_bytes(*desc);
         char* w = static_cast<char*>(workspace);
@@ -496,8 +508,12 @@ static int merge_shapes(int H, int W, int mh, int mw, int wh, int ww, int* Hm, i
 
 static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const float* const* in, float* const* out,
                             int B, int H, int W, int Cin, int Cout, int mh, int mw, int wh, int ww, void* workspace,
-                            size_t workspace_bytes, hipStream_t stream, int fast = 0, const void* const* prr = nullptr) {
+                            size_t workspace_bytes, hipStream_t stream, int fast = 0, const void* const* prr = nullptr,
+                            const swf_block_stream_params* const* first_blk = nullptr, bool* ln1_ready = nullptr) {
     // prr: per-stream packed images of the register-resident kernel (pack_patch_rr; the model path has them) or nullptr
+    // first_blk / ln1_ready: the parameters of the deep-level block that runs next on this workspace; when the whole-row deep patch
+    // kernel runs, it also leaves that block's LN1 planes (deep_ln1_planes) and sets *ln1_ready
+    if (ln1_ready) *ln1_ready = false;
     int Hm, Wm, Ho, Wo;
     SWF_TRY(merge_shapes(H, W, mh, mw, wh, ww, &Hm, &Wm, &Ho, &Wo));
     const int64_t N = (int64_t)B * Ho * Wo;
@@ -525,7 +541,22 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
             SWF_TRY(launch_deep_patch(d, prr, nstream, stream, zr));
             return launch_layernorm(lz, nstream, N, Cout, 1, stream);
         }
-        if (use_dp) return launch_deep_patch(d, prr, nstream, stream);
+        if (use_dp) {
+            DeepPatchExtra ex{};
+            const bool with_ln = first_blk && ln1_ready && first_blk[0] && (nstream == 1 || first_blk[1]) && workspace;
+            if (with_ln) {
+                Carver wl(workspace, workspace_bytes);
+                bf16_raw *hi[2] = {nullptr, nullptr}, *lo[2] = {nullptr, nullptr};
+                deep_ln1_planes(wl, N, Cout, nstream, hi, lo);
+                if (!wl.ok()) return fail(SWF_ERR_WORKSPACE, "patch-merge workspace too small for the LN1 planes (need %zu B)", wl.used);
+                for (int s = 0; s < nstream; ++s) {
+                    ex.ln_gamma[s] = first_blk[s]->ln1.gamma; ex.ln_beta[s] = first_blk[s]->ln1.beta; ex.ln_hi[s] = hi[s]; ex.ln_lo[s] = lo[s];
+                }
+            }
+            SWF_TRY(launch_deep_patch(d, prr, nstream, stream, nullptr, with_ln ? &ex : nullptr));
+            if (with_ln) *ln1_ready = true;
+            return SWF_OK;
+        }
         return launch_patch_fused(d, nstream, stream);
     }
     Carver ws(workspace, workspace_bytes);
@@ -552,7 +583,11 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
 static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, const float* const* in,
                               const float* const* skip, float* const* out, int B, int Hp, int Wp, int Hm, int Wm, int Cin,
                               int Cout, int mh, int mw, int Hout, int Wout, void* workspace, size_t workspace_bytes,
-                              hipStream_t stream, int fast = 0, const void* const* prr = nullptr) {
+                              hipStream_t stream, int fast = 0, const void* const* prr = nullptr, const char* warm = nullptr,
+                              size_t warm_pb = 0, bool* warmed = nullptr) {
+    // warm / warm_pb: packed images (x, then y at + warm_pb) of the block that runs next; the whole-row deep patch kernel touches them
+    // at its end and sets *warmed (the caller otherwise spends a launch on it)
+    if (warmed) *warmed = false;
     if (Hm <= 0 || Wm <= 0 || Hm > Hp || Wm > Wp) return fail(SWF_ERR_BAD_SHAPE, "crop %dx%d of %dx%d", Hm, Wm, Hp, Wp);
     if (Hout <= 0 || Wout <= 0 || Hout > Hm * mh || Wout > Wm * mw)
         return fail(SWF_ERR_BAD_SHAPE, "output %dx%d larger than the unmerged map %dx%d", Hout, Wout, Hm * mh, Wm * mw);
@@ -589,7 +624,11 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
                 return launch_ln_unmerge_scatter(lz, sz, nstream, B, Hm, Wm, Cout, mh, mw, Hout, Wout, stream);
             }
         } else if (use_dp) {
-            return launch_deep_patch(d, prr, nstream, stream);
+            DeepPatchExtra ex{};
+            if (warm && warm_pb && nstream == 2) { ex.warm[0] = warm; ex.warm[1] = warm + warm_pb; ex.warm_bytes = warm_pb; }
+            SWF_TRY(launch_deep_patch(d, prr, nstream, stream, nullptr, ex.warm[0] ? &ex : nullptr));
+            if (warmed && ex.warm[0]) *warmed = true;
+            return SWF_OK;
         }
         if (!use_dp) return launch_patch_fused(d, nstream, stream);
     }
@@ -798,7 +837,11 @@ static swf_block_desc level_block_desc(const swf_model_desc* d, int lvl, bool en
 static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                             const float* x_in, const float* y_in, float* x_out, float* y_out, int B, int H, int W,
                             void* workspace, size_t workspace_bytes, hipStream_t stream, const char* packed = nullptr,
-                            const char* after = nullptr, size_t after_pb = 0, int32_t* equal_flags = nullptr) {
+                            const char* after = nullptr, size_t after_pb = 0, int32_t* equal_flags = nullptr,
+                            const swf_block_stream_params* const* stage_next = nullptr, bool* ln1_io = nullptr) {
+    // `stage_next` / `ln1_io` (deep levels): the first block's parameters of the stage that runs next on the same workspace with the
+    // same map (the decoder stage behind the deepest encoder stage), so that this stage's last MLP reduce leaves that block's LN1
+    // planes; *ln1_io says on entry whether this stage's first block finds its planes in place, on return whether the next does
     // `equal_flags` (device, 2 entries pre-set to 1, or nullptr): cleared when the inputs of the stage's two cross blocks
     // differ somewhere — the reference's first-forward check `(x == y).all()` (a005:111-118)
     // `after`: packed images (x, then y at + after_pb) of the first block of the NEXT stage when that is a fused-kernel stage
@@ -806,7 +849,7 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
     const float* xi = x_in;
     const float* yi = y_in;
     const size_t pb = packed ? block_packed_bytes(*desc) : 0;
-    bool ln1_ready = false;   // deep levels: block i's MLP reduce also writes block i+1's LN1 planes
+    bool ln1_ready = ln1_io ? *ln1_io : false;   // deep levels: block i's MLP reduce also writes block i+1's LN1 planes
     // Kernels that cannot run a cross block in place (window_block_out_of_place): the two cross blocks ping-pong through two
     // temporary maps at the END of the workspace (block 2: maps -> temporaries, block 3: temporaries -> outputs) instead of
     // each going through basic_block_impl's temporary-and-copy route
@@ -832,14 +875,17 @@ static int block_pair4_impl(const swf_block_desc* desc, const swf_block_stream_p
         const void* nkx = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 2) * pb : (i == 3 ? after : nullptr);   // next block: warmed in L2
         const void* nky = (packed && pb && i < 3) ? packed + (size_t)(2 * i + 3) * pb : (i == 3 && after ? after + after_pb : nullptr);
         const swf_block_stream_params* nxt[2] = {i < 3 ? &px[i + 1] : nullptr, (i < 3 && py) ? &py[i + 1] : nullptr};
+        const bool chain_out = i == 3 && stage_next && stage_next[0] && (!py || stage_next[1]);
+        if (chain_out) { nxt[0] = stage_next[0]; nxt[1] = py ? stage_next[1] : nullptr; }
         if (equal_flags && d.cross && py)
             SWF_TRY(launch_all_equal(xi, yi, (int64_t)B * H * W * desc->attn.channels, equal_flags + (i - 2), stream));
         float* xo = (tx && i == 2) ? tx : x_out;
         float* yo = (tx && i == 2) ? ty : y_out;
         SWF_TRY(basic_block_impl(&d, &px[i], py ? &py[i] : nullptr, xi, yi, xo, yo, B, H, W, workspace, tx ? ws_left : workspace_bytes, stream, pkx, pky,
-                                 nkx, nky, i == 3 ? after_pb : 0, i < 3 ? nxt : nullptr, &ln1_ready));
+                                 nkx, nky, i == 3 ? after_pb : 0, (i < 3 || chain_out) ? nxt : nullptr, &ln1_ready));
         xi = xo; yi = yo;
     }
+    if (ln1_io) *ln1_io = ln1_ready;
     return SWF_OK;
 }
 
@@ -1215,16 +1261,22 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
 
     // encoder (a013:215-220)
     const float* cur[2] = {ir, vis};
+    bool ln1_carry = false;   // deep levels: the LN1 planes of the next block to run are in place (deep_ln1_planes)
+    swf_block_stream_params dpx0 = make_stream_params(arena, L->dec_blk[0][0][0]), dpy0 = make_stream_params(arena, L->dec_blk[0][0][1]);
+    const swf_block_stream_params* dec_first[2] = {&dpx0, &dpy0};   // first block of the decoder stage that follows the deepest encoder stage
     for (int s = 0; s < n; ++s) {
         swf_patch_params pm[2] = {patch_params(L->enc_patch[s][0]), patch_params(L->enc_patch[s][1])};
         const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
         const void* prr_enc[2] = {packed ? packed + plan.penc[s] : nullptr, packed ? packed + plan.penc[s] + plan.penc_b[s] : nullptr};
-        SWF_TRY(patch_merge_impl(pmp, 2, cur, act[s], B, ls[s].Hin, ls[s].Win, desc->in_dims[s], desc->out_dims[s], desc->merge_h,
-                                 desc->merge_w, desc->win_h, desc->win_w, scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST,
-                                 (packed && plan.penc_b[s]) ? prr_enc : nullptr));
         swf_block_stream_params px[4], py[4];
         for (int i = 0; i < 4; ++i) { px[i] = make_stream_params(arena, L->enc_blk[s][i][0]); py[i] = make_stream_params(arena, L->enc_blk[s][i][1]); }
         swf_block_desc bd = level_block_desc(desc, s, true);
+        const swf_block_stream_params* first_blk[2] = {&px[0], &py[0]};
+        const bool deep_stage = packed && desc->precision == SWF_PREC_FAST && window_block_packed_bytes(bd) == 0 && deep_block_supported(bd);
+        ln1_carry = false;
+        SWF_TRY(patch_merge_impl(pmp, 2, cur, act[s], B, ls[s].Hin, ls[s].Win, desc->in_dims[s], desc->out_dims[s], desc->merge_h,
+                                 desc->merge_w, desc->win_h, desc->win_w, scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST,
+                                 (packed && plan.penc_b[s]) ? prr_enc : nullptr, deep_stage ? first_blk : nullptr, deep_stage ? &ln1_carry : nullptr));
         // the first block of the next fused-kernel stage is warmed by this stage's last block
         const char* after = nullptr;
         size_t after_pb = 0;
@@ -1232,9 +1284,12 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
             swf_block_desc nb = level_block_desc(desc, s + 1, true);
             if (window_block_packed_bytes(nb) && plan.enc_on[s + 1]) { after = packed + plan.enc[s + 1]; after_pb = window_block_packed_bytes(nb); }
         }
+        // the deepest stage hands the LN1 planes of the decoder's first block (same level, same map, same workspace) to it
+        const bool chain = deep_stage && s == n - 1;
         SWF_TRY(block_pair4_impl(&bd, px, py, act[s][0], act[s][1], act[s][0], act[s][1], B, ls[s].Ho, ls[s].Wo, scratch, scratch_bytes, stream,
                                  (packed && plan.enc_on[s]) ? packed + plan.enc[s] : nullptr, after, after_pb,
-                                 equal_flags ? equal_flags + 2 * s : nullptr));
+                                 equal_flags ? equal_flags + 2 * s : nullptr, chain ? dec_first : nullptr, deep_stage ? &ln1_carry : nullptr));
+        if (!chain) ln1_carry = false;
         cur[0] = act[s][0]; cur[1] = act[s][1];
     }
     // decoder (a013:221-227): the skip add of stage j+1 is folded into stage j's unmerge epilogue,
@@ -1250,11 +1305,13 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
             swf_block_desc nb = level_block_desc(desc, n - 2 - j, false);
             if (window_block_packed_bytes(nb) && plan.dec_on[j + 1]) { after = packed + plan.dec[j + 1]; after_pb = window_block_packed_bytes(nb); }
         }
+        bool ln1_in = j == 0 ? ln1_carry : false;   // (only the stage behind the deepest encoder stage can find its planes in place)
         SWF_TRY(block_pair4_impl(&bd, px, py, act[lvl][0], act[lvl][1], act[lvl][0], act[lvl][1], B, ls[lvl].Ho, ls[lvl].Wo, scratch, scratch_bytes, stream,
                                  (packed && plan.dec_on[j]) ? packed + plan.dec[j] : nullptr, after, after_pb,
-                                 equal_flags ? equal_flags + 2 * (n + j) : nullptr));
-        // a deep-level stage cannot warm its successor from inside a block kernel: one small launch does it
-        if (after && window_block_packed_bytes(bd) == 0) SWF_TRY(launch_l2_warm(after, 2 * after_pb, stream));
+                                 equal_flags ? equal_flags + 2 * (n + j) : nullptr, nullptr, &ln1_in));
+        // a deep-level stage cannot warm its successor from inside a block kernel: its patch layer does it (or one small launch)
+        const bool warm_next = after && window_block_packed_bytes(bd) == 0;
+        bool warmed = false;
         swf_patch_params pm[2] = {patch_params(L->dec_patch[j][0]), patch_params(L->dec_patch[j][1])};
         const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
         const float* ins[2] = {act[lvl][0], act[lvl][1]};
@@ -1263,7 +1320,9 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
         const void* prr_dec[2] = {packed ? packed + plan.pdec[j] : nullptr, packed ? packed + plan.pdec[j] + plan.pdec_b[j] : nullptr};
         SWF_TRY(patch_unmerge_impl(pmp, 2, ins, lvl > 0 ? skip : nullptr, outs, B, ls[lvl].Ho, ls[lvl].Wo, ls[lvl].Hm, ls[lvl].Wm,
                                    desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, ls[lvl].Hin, ls[lvl].Win,
-                                   scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST, (packed && plan.pdec_b[j]) ? prr_dec : nullptr));
+                                   scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST, (packed && plan.pdec_b[j]) ? prr_dec : nullptr,
+                                   warm_next ? after : nullptr, warm_next ? after_pb : 0, &warmed));
+        if (warm_next && !warmed) SWF_TRY(launch_l2_warm(after, 2 * after_pb, stream));
     }
     swf_head_params hp{arena + L->h_c1w, arena + L->h_c1b, arena + L->h_g, arena + L->h_b, arena + L->h_m, arena + L->h_v,
                        arena + L->h_c2w, arena + L->h_c2b};
