@@ -470,6 +470,37 @@ def test_basic_block_wide_vs_oracle(case, precision):
     assert torch.equal(ox, ox2) and torch.equal(oy, oy2)
 
 
+_SINGLE = [  # single-path blocks (use_dual_path=False, a005:54-76): C, heads, d, hidden, (B,H,W), shift
+    (24, 8, 3, 96, (2, 16, 16), True),
+    (96, 8, 12, 384, (1, 16, 8), False),
+    (192, 8, 24, 768, (2, 8, 16), True),     # deep path with one stream: qkv_attn, fused MLP with a hidden split
+    (384, 8, 48, 1536, (2, 8, 8), True),     # level-4 launches with one stream: rows x fragment-major Q/K/V, attention + projection, 8-wave MLP
+    (384, 8, 48, 768, (1, 8, 16), False),
+]
+
+
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+@pytest.mark.parametrize("case", _SINGLE, ids=[f"C{c[0]}_hid{c[3]}_s{int(c[5])}" for c in _SINGLE])
+def test_basic_block_single_stream_vs_oracle(case, precision):
+    """BasicBlock.forward(x) of a single-path block: the x half of the dual-path oracle with self attention (the y stream cannot
+    reach it), on the same weights."""
+    c, nh, d, hid, shape, shift = case
+    b, h, w = shape
+    dual = BasicBlock(c, nh, d, (8, 8), shift, True, False, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
+    load_recipe_into(dual, seed=23, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in dual.state_dict().items()}
+    x, y = G.randn((b, c, h, w), 611), G.randn((b, c, h, w), 612)
+    rx, _ = O.basic_block(sd, "", x, y, cross=False, shift=shift, num_heads=nh, dims_per_head=d, window_size=(8, 8))
+    m = BasicBlock(c, nh, d, (8, 8), shift, False, False, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
+    m.load_state_dict({k: v for k, v in sd.items() if k in m.state_dict()})
+    m.to(DEV)
+    m.precision = precision
+    out = m(x.to(DEV))
+    ox = out[0] if isinstance(out, tuple) else out
+    tol, tmax = (TOL_FP32, None) if precision == "fp32" else (TOL_FAST_L2, TOL_FAST_MAX)
+    _close(ox, rx, tol, tmax)
+
+
 _WIN7 = [  # 7x7 windows (the reference's default, A000_CONFIG.py:55) at every level width: C, heads, d, hidden, (B,H,W), shift, cross
     (24, 8, 3, 96, (2, 14, 21), True, True),
     (48, 8, 6, 192, (2, 14, 21), True, True),
