@@ -25,6 +25,11 @@ struct DeepPatchExtra {
 int launch_deep_patch(const PatchFusedDesc& d, const void* const* packed, int nstream, hipStream_t stream, float* const* raw_out = nullptr,
                       const DeepPatchExtra* extra = nullptr);
 
+// Second launch of a column-sliced layer: LayerNorm (+ ELU, + depth-to-space scatter and skip in the decoder) of the conv rows in
+// raw[s], and — when extra carries them — the next block's LN1 of the finished rows / pixels as split-bf16 planes (encoder: N = 384
+// rows; decoder: N = 768 -> pixels of 192 channels).  d as for launch_deep_patch.
+int launch_deep_patch_finish(const PatchFusedDesc& d, float* const* raw, int nstream, hipStream_t stream, const DeepPatchExtra* extra = nullptr);
+
 // Q/K/V projections of a level-4 block (C = heads * head_dim = 384) on the same kernel: LayerNorm planes [M][384] in, the attention
 // core's fp16 operands out (Q pre-scaled by qscale).  Replaces launch_gemm_sp(..., SP_EPI_QKV16).
 struct DeepQkvArgs {

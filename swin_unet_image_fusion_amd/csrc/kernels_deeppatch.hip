@@ -370,6 +370,138 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
     DP_STAMP(10);
 }
 
+// ---- row finishers of the column-sliced ("raw") layers: one wave per conv output row ---------------------------------------
+// Encoder (N = 384): LayerNorm + ELU -> out rows, then (optionally) the next block's LN1 of those rows as split-bf16 planes.
+// Decoder (N = 768 = 4 sub-pixels x 192): LayerNorm over the whole row + ELU, depth-to-space scatter + skip -> out pixels, then
+// (optionally) the next block's LN1 per output pixel as planes.  Lane l holds 16-byte groups l, l + 64, (l + 128): in the decoder
+// group index = 48 p + q with p = l >> 4 the sub-pixel, so a pixel's 192 channels live in 16 consecutive lanes.
+struct FinArgs {
+    const float* z[2]; float* out[2]; const float* skip[2];
+    const float* g1[2]; const float* b1[2];
+    const float* g2[2]; const float* b2[2]; bf16* hi[2]; bf16* lo[2];   // optional second LayerNorm (planes), or nullptr
+    int M, Hm, Wm, Ho, Wo;
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void dp_finish_enc_kernel(FinArgs a) {
+    constexpr int N = 384, NG = N / 4;   // 96 groups: lanes 0..63 hold group l, lanes 0..31 also group l + 64
+    const int s = blockIdx.y, lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const bool two = lane + 64 < NG;
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+    const float* zr = a.z[s] + (size_t)m * N;
+    f32x4 v0 = *reinterpret_cast<const f32x4*>(zr + 4 * lane), v1 = two ? *reinterpret_cast<const f32x4*>(zr + 4 * (lane + 64)) : zero4;
+    const f32x4 g0 = *reinterpret_cast<const f32x4*>(a.g1[s] + 4 * lane), c0 = *reinterpret_cast<const f32x4*>(a.b1[s] + 4 * lane);
+    const f32x4 g1 = two ? *reinterpret_cast<const f32x4*>(a.g1[s] + 4 * (lane + 64)) : zero4, c1 = two ? *reinterpret_cast<const f32x4*>(a.b1[s] + 4 * (lane + 64)) : zero4;
+    const float mean = wave_sum((v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3])) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d0 = v0[j] - mean, d1 = two ? v1[j] - mean : 0.f; q += d0 * d0 + d1 * d1; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + 1e-5f);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        v0[j] = elu_fast((v0[j] - mean) * rstd * g0[j] + c0[j]);
+        v1[j] = two ? elu_fast((v1[j] - mean) * rstd * g1[j] + c1[j]) : 0.f;
+    }
+    float* orow = a.out[s] + (size_t)m * N;
+    *reinterpret_cast<f32x4*>(orow + 4 * lane) = v0;
+    if (two) *reinterpret_cast<f32x4*>(orow + 4 * (lane + 64)) = v1;
+    if (!a.hi[s]) return;
+    const float mean2 = wave_sum((v0[0] + v0[1]) + (v0[2] + v0[3]) + (v1[0] + v1[1]) + (v1[2] + v1[3])) * (1.0f / N);
+    float q2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { const float d0 = v0[j] - mean2, d1 = two ? v1[j] - mean2 : 0.f; q2 += d0 * d0 + d1 * d1; }
+    const float rstd2 = 1.0f / sqrtf(wave_sum(q2) * (1.0f / N) + 1e-5f);
+#pragma unroll
+    for (int k = 0; k < 2; ++k) {
+        if (k == 1 && !two) break;
+        const int c = 4 * (lane + 64 * k);
+        const f32x4 v = k ? v1 : v0;
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g2[s] + c), bb = *reinterpret_cast<const f32x4*>(a.b2[s] + c);
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float n = (v[j] - mean2) * rstd2 * g[j] + bb[j];
+            h[j] = (bf16)n;
+            l[j] = (bf16)(n - (float)h[j]);
+        }
+        *reinterpret_cast<bf16x4*>(a.hi[s] + (size_t)m * N + c) = h;
+        *reinterpret_cast<bf16x4*>(a.lo[s] + (size_t)m * N + c) = l;
+    }
+}
+
+__global__ __launch_bounds__(256) void dp_finish_dec_kernel(FinArgs a) {
+    constexpr int CO = 192, N = 4 * CO, GP = CO / 4;   // 48 groups per sub-pixel: lane (p = l >> 4, q = l & 15) holds groups q, q + 16, q + 32 of sub-pixel p
+    const int s = blockIdx.y, lane = threadIdx.x & 63, m = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (m >= a.M) return;
+    const int p = lane >> 4, q0 = lane & 15;
+    const int mx = m % a.Wm, t = m / a.Wm, my = t % a.Hm, b = t / a.Hm;
+    const int y = 2 * my + (p >> 1), xo = 2 * mx + (p & 1);
+    const bool inside = y < a.Ho && xo < a.Wo;
+    const size_t pix = ((size_t)(b * a.Ho + y) * a.Wo + xo) * CO;
+    const float* zr = a.z[s] + (size_t)m * N + p * CO;
+    f32x4 v[3], sk[3];
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = 4 * (q0 + 16 * i);
+        v[i] = *reinterpret_cast<const f32x4*>(zr + c);
+        sk[i] = (a.skip[s] && inside) ? *reinterpret_cast<const f32x4*>(a.skip[s] + pix + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+        sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    const float mean = wave_sum(sum) * (1.0f / N);
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean; q += d * d; }
+    const float rstd = 1.0f / sqrtf(wave_sum(q) * (1.0f / N) + 1e-5f);
+    float sum2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = p * CO + 4 * (q0 + 16 * i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g1[s] + c), bb = *reinterpret_cast<const f32x4*>(a.b1[s] + c);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) v[i][j] = elu_fast((v[i][j] - mean) * rstd * g[j] + bb[j]) + sk[i][j];
+        if (inside) *reinterpret_cast<f32x4*>(a.out[s] + pix + 4 * (q0 + 16 * i)) = v[i];
+        sum2 += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    if (!a.hi[s]) return;
+    // LN1 of the output pixel: its 192 channels sit in the 16 lanes of sub-pixel p
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) sum2 += __shfl_xor(sum2, o);
+    const float mean2 = sum2 * (1.0f / CO);
+    float q2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 3; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { const float d = v[i][j] - mean2; q2 += d * d; }
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) q2 += __shfl_xor(q2, o);
+    const float rstd2 = 1.0f / sqrtf(q2 * (1.0f / CO) + 1e-5f);
+    if (!inside) return;
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+        const int c = 4 * (q0 + 16 * i);
+        const f32x4 g = *reinterpret_cast<const f32x4*>(a.g2[s] + c), bb = *reinterpret_cast<const f32x4*>(a.b2[s] + c);
+        bf16x4 h, l;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float n = (v[i][j] - mean2) * rstd2 * g[j] + bb[j];
+            h[j] = (bf16)n;
+            l[j] = (bf16)(n - (float)h[j]);
+        }
+        *reinterpret_cast<bf16x4*>(a.hi[s] + pix + c) = h;
+        *reinterpret_cast<bf16x4*>(a.lo[s] + pix + c) = l;
+    }
+    (void)GP;
+}
+
 // fp32 [N][K] -> fragment-major split planes: block (32-row tile rt, k16 step ks) = 64 lanes x 8 bf16, lane 32 hf + r holds
 // row 32 rt + r, k = 16 ks + 8 hf .. + 7
 __global__ __launch_bounds__(256) void dp_pack_kernel(const float* __restrict__ src, bf16* __restrict__ hi, bf16* __restrict__ lo, int N, int K) {
@@ -409,6 +541,25 @@ int launch_t(const DpArgs& a, int nstream, hipStream_t stream) {
 }
 
 }  // namespace
+
+int launch_deep_patch_finish(const PatchFusedDesc& d, float* const* raw, int nstream, hipStream_t stream, const DeepPatchExtra* extra) {
+    const int i = shape_index(d.decoder, d.Cin, d.Cout, d.mh, d.mw);
+    if (i < 0 || !kShapes[i].raw) return fail(SWF_ERR_UNSUPPORTED, "deep_patch_finish: not a column-sliced shape");
+    FinArgs a{};
+    for (int s = 0; s < nstream; ++s) {
+        if (!raw || !raw[s] || !d.out[s] || !d.gamma[s] || !d.beta[s]) return fail(SWF_ERR_NULL, "deep_patch_finish: NULL operand (stream %d)", s);
+        a.z[s] = raw[s]; a.out[s] = d.out[s]; a.skip[s] = d.skip[s]; a.g1[s] = d.gamma[s]; a.b1[s] = d.beta[s];
+        if (extra && extra->ln_hi[s]) {
+            a.g2[s] = extra->ln_gamma[s]; a.b2[s] = extra->ln_beta[s];
+            a.hi[s] = reinterpret_cast<bf16*>(extra->ln_hi[s]); a.lo[s] = reinterpret_cast<bf16*>(extra->ln_lo[s]);
+        }
+    }
+    a.M = (int)d.M; a.Hm = d.Hm; a.Wm = d.Wm; a.Ho = d.Ho; a.Wo = d.Wo;
+    const dim3 grid((unsigned)((d.M + 3) / 4), nstream);
+    if (d.decoder) hipLaunchKernelGGL(dp_finish_dec_kernel, grid, dim3(256), 0, stream, a);
+    else hipLaunchKernelGGL(dp_finish_enc_kernel, grid, dim3(256), 0, stream, a);
+    return check_launch("deep_patch_finish");
+}
 
 bool deep_qkv_supported(const swf_block_desc& d) {
     static const bool off = std::getenv("SWF_NO_DEEP_QKV") != nullptr;   // A/B switch (tools)

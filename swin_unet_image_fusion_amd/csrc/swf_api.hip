@@ -532,14 +532,24 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
         d.decoder = 0; d.B = B; d.H = H; d.W = W; d.Cin = Cin; d.mh = mh; d.mw = mw; d.Hm = Hm; d.Wm = Wm; d.Ho = Ho; d.Wo = Wo;
         d.K = K; d.N = Cout; d.Cout = Cout; d.M = N;
         if (use_prr) return launch_patch_rr(d, prr, nstream, stream);
-        if (use_dp && deep_patch_raw(0, Cin, Cout, mh, mw)) {   // conv over column slices, then LayerNorm + ELU as a second launch
+        if (use_dp && deep_patch_raw(0, Cin, Cout, mh, mw)) {   // conv over column slices, then LayerNorm + ELU (+ the next block's LN1) as a second launch
             Carver wz(workspace, workspace_bytes);
+            DeepPatchExtra ex{};
+            const bool with_ln = first_blk && ln1_ready && first_blk[0] && (nstream == 1 || first_blk[1]);
+            if (with_ln) {   // the planes sit at the start of the workspace (deep_ln1_planes), the conv rows behind them
+                bf16_raw *hi[2] = {nullptr, nullptr}, *lo[2] = {nullptr, nullptr};
+                deep_ln1_planes(wz, N, Cout, nstream, hi, lo);
+                for (int s = 0; s < nstream; ++s) {
+                    ex.ln_gamma[s] = first_blk[s]->ln1.gamma; ex.ln_beta[s] = first_blk[s]->ln1.beta; ex.ln_hi[s] = hi[s]; ex.ln_lo[s] = lo[s];
+                }
+            }
             float* zr[2] = {nullptr, nullptr};
-            LnBatch lz{};
-            for (int s = 0; s < nstream; ++s) { zr[s] = wz.floats(N * Cout); lz.p[s] = LnProb{zr[s], out[s], p[s]->ln.gamma, p[s]->ln.beta}; }
+            for (int s = 0; s < nstream; ++s) zr[s] = wz.floats(N * Cout);
             if (!wz.ok()) return fail(SWF_ERR_WORKSPACE, "patch-merge workspace too small (need %zu B)", wz.used);
             SWF_TRY(launch_deep_patch(d, prr, nstream, stream, zr));
-            return launch_layernorm(lz, nstream, N, Cout, 1, stream);
+            SWF_TRY(launch_deep_patch_finish(d, zr, nstream, stream, with_ln ? &ex : nullptr));
+            if (with_ln) *ln1_ready = true;
+            return SWF_OK;
         }
         if (use_dp) {
             DeepPatchExtra ex{};
@@ -584,7 +594,11 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
                               const float* const* skip, float* const* out, int B, int Hp, int Wp, int Hm, int Wm, int Cin,
                               int Cout, int mh, int mw, int Hout, int Wout, void* workspace, size_t workspace_bytes,
                               hipStream_t stream, int fast = 0, const void* const* prr = nullptr, const char* warm = nullptr,
-                              size_t warm_pb = 0, bool* warmed = nullptr) {
+                              size_t warm_pb = 0, bool* warmed = nullptr, const swf_block_stream_params* const* next_blk = nullptr,
+                              bool* ln1_ready = nullptr) {
+    // next_blk / ln1_ready: the first block of the decoder stage that runs next (a deep-level stage on this workspace): the
+    // column-sliced layer's second launch also leaves that block's LN1 planes (deep_ln1_planes over the output pixels)
+    if (ln1_ready) *ln1_ready = false;
     // warm / warm_pb: packed images (x, then y at + warm_pb) of the block that runs next; the whole-row deep patch kernel touches them
     // at its end and sets *warmed (the caller otherwise spends a launch on it)
     if (warmed) *warmed = false;
@@ -608,21 +622,24 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
         d.decoder = 1; d.B = B; d.H = Hp; d.W = Wp; d.Cin = Cin; d.mh = mh; d.mw = mw; d.Hm = Hm; d.Wm = Wm; d.Ho = Hout; d.Wo = Wout;
         d.K = Cin; d.N = Kz; d.Cout = Cout; d.M = N;
         if (use_prr) return launch_patch_rr(d, prr, nstream, stream);
-        if (use_dp && deep_patch_raw(1, Cin, Cout, mh, mw)) {   // conv over column slices, then LayerNorm + scatter + ELU (+ skip)
+        if (use_dp && deep_patch_raw(1, Cin, Cout, mh, mw)) {   // conv over column slices, then LayerNorm + scatter + ELU (+ skip) (+ the next block's LN1)
             Carver wz(workspace, workspace_bytes);
+            DeepPatchExtra ex{};
+            const bool with_ln = next_blk && ln1_ready && next_blk[0] && (nstream == 1 || next_blk[1]);
+            if (with_ln) {
+                bf16_raw *hi[2] = {nullptr, nullptr}, *lo[2] = {nullptr, nullptr};
+                deep_ln1_planes(wz, (int64_t)B * Hout * Wout, Cout, nstream, hi, lo);
+                for (int s = 0; s < nstream; ++s) {
+                    ex.ln_gamma[s] = next_blk[s]->ln1.gamma; ex.ln_beta[s] = next_blk[s]->ln1.beta; ex.ln_hi[s] = hi[s]; ex.ln_lo[s] = lo[s];
+                }
+            }
             float* zr[2] = {nullptr, nullptr};
-            LnBatch lz{};
-            PtrPair sz{};
-            for (int s = 0; s < nstream; ++s) {
-                zr[s] = wz.floats(N * Kz);
-                lz.p[s] = LnProb{zr[s], nullptr, p[s]->ln.gamma, p[s]->ln.beta};
-                sz.in[s] = zr[s]; sz.out[s] = out[s]; sz.aux[s] = skip ? skip[s] : nullptr;
-            }
+            for (int s = 0; s < nstream; ++s) zr[s] = wz.floats(N * Kz);
             if (!wz.ok()) return fail(SWF_ERR_WORKSPACE, "patch-unmerge workspace too small (need %zu B)", wz.used);
-            if (ln_unmerge_scatter_supported(lz, sz, nstream, Cout, mh, mw)) {
-                SWF_TRY(launch_deep_patch(d, prr, nstream, stream, zr));
-                return launch_ln_unmerge_scatter(lz, sz, nstream, B, Hm, Wm, Cout, mh, mw, Hout, Wout, stream);
-            }
+            SWF_TRY(launch_deep_patch(d, prr, nstream, stream, zr));
+            SWF_TRY(launch_deep_patch_finish(d, zr, nstream, stream, with_ln ? &ex : nullptr));
+            if (with_ln) *ln1_ready = true;
+            return SWF_OK;
         } else if (use_dp) {
             DeepPatchExtra ex{};
             if (warm && warm_pb && nstream == 2) { ex.warm[0] = warm; ex.warm[1] = warm + warm_pb; ex.warm_bytes = warm_pb; }
@@ -1305,13 +1322,24 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
             swf_block_desc nb = level_block_desc(desc, n - 2 - j, false);
             if (window_block_packed_bytes(nb) && plan.dec_on[j + 1]) { after = packed + plan.dec[j + 1]; after_pb = window_block_packed_bytes(nb); }
         }
-        bool ln1_in = j == 0 ? ln1_carry : false;   // (only the stage behind the deepest encoder stage can find its planes in place)
+        bool ln1_in = ln1_carry;   // planes left by the deepest encoder stage (j == 0) or by the unmerge layer of the stage before
         SWF_TRY(block_pair4_impl(&bd, px, py, act[lvl][0], act[lvl][1], act[lvl][0], act[lvl][1], B, ls[lvl].Ho, ls[lvl].Wo, scratch, scratch_bytes, stream,
                                  (packed && plan.dec_on[j]) ? packed + plan.dec[j] : nullptr, after, after_pb,
                                  equal_flags ? equal_flags + 2 * (n + j) : nullptr, nullptr, &ln1_in));
         // a deep-level stage cannot warm its successor from inside a block kernel: its patch layer does it (or one small launch)
         const bool warm_next = after && window_block_packed_bytes(bd) == 0;
         bool warmed = false;
+        // the next decoder stage, when it is a deep-level one, finds its first block's LN1 planes written by this stage's unmerge layer
+        swf_block_stream_params npx0{}, npy0{};
+        bool next_deep = false;
+        if (packed && desc->precision == SWF_PREC_FAST && j + 1 < n) {
+            swf_block_desc nb = level_block_desc(desc, n - 2 - j, false);
+            nb.precision = SWF_PREC_FAST;
+            next_deep = window_block_packed_bytes(nb) == 0 && deep_block_supported(nb);
+            if (next_deep) { npx0 = make_stream_params(arena, L->dec_blk[j + 1][0][0]); npy0 = make_stream_params(arena, L->dec_blk[j + 1][0][1]); }
+        }
+        const swf_block_stream_params* next_first[2] = {&npx0, &npy0};
+        ln1_carry = false;
         swf_patch_params pm[2] = {patch_params(L->dec_patch[j][0]), patch_params(L->dec_patch[j][1])};
         const swf_patch_params* pmp[2] = {&pm[0], &pm[1]};
         const float* ins[2] = {act[lvl][0], act[lvl][1]};
@@ -1321,7 +1349,8 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
         SWF_TRY(patch_unmerge_impl(pmp, 2, ins, lvl > 0 ? skip : nullptr, outs, B, ls[lvl].Ho, ls[lvl].Wo, ls[lvl].Hm, ls[lvl].Wm,
                                    desc->out_dims[lvl], desc->in_dims[lvl], desc->merge_h, desc->merge_w, ls[lvl].Hin, ls[lvl].Win,
                                    scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST, (packed && plan.pdec_b[j]) ? prr_dec : nullptr,
-                                   warm_next ? after : nullptr, warm_next ? after_pb : 0, &warmed));
+                                   warm_next ? after : nullptr, warm_next ? after_pb : 0, &warmed, next_deep ? next_first : nullptr,
+                                   next_deep ? &ln1_carry : nullptr));
         if (warm_next && !warmed) SWF_TRY(launch_l2_warm(after, 2 * after_pb, stream));
     }
     swf_head_params hp{arena + L->h_c1w, arena + L->h_c1b, arena + L->h_g, arena + L->h_b, arena + L->h_m, arena + L->h_v,
