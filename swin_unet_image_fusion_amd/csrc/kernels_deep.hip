@@ -361,7 +361,7 @@ DeepSizes deep_sizes(const swf_block_desc& d) {
     DeepSizes s;
     s.qkv = HD * C; s.proj = C * HD; s.w1 = hid * C; s.w2 = C * hid;
     s.fm = mlp_fused_supported((int)C, (int)hid) ? s.w1 + s.w2 : 0;   // fragment-major copies of fc1 | fc2
-    s.pfm = attnproj_supported(d) && HD == C ? s.proj : 0;              // fragment-major copy of Wproj (kernels_attnproj.hip)
+    s.pfm = ((attnproj_supported(d) && HD == C) || deep_proj_supported(d)) ? s.proj : 0;   // fragment-major copy of Wproj (kernels_attnproj.hip, launch_deep_proj)
     s.qfm = deep_qkv_supported(d) ? 3 * s.qkv : 0;                        // fragment-major Wq | Wk | Wv (kernels_deeppatch.hip)
     s.total = 3 * s.qkv + s.proj + s.w1 + s.w2 + s.fm + s.pfm + s.qfm;
     return s;

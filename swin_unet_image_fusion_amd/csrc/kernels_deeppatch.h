@@ -34,12 +34,24 @@ int launch_deep_patch_finish(const PatchFusedDesc& d, float* const* raw, int nst
 // core's fp16 operands out (Q pre-scaled by qscale).  Replaces launch_gemm_sp(..., SP_EPI_QKV16).
 struct DeepQkvArgs {
     const unsigned short* xn_hi[2]; const unsigned short* xn_lo[2];   // LayerNorm planes (bf16 hi / lo) of each stream
-    const unsigned short* w_hi[2]; const unsigned short* w_lo[2];     // Wq | Wk | Wv stacked [1152][384], fragment-major (DeepWeights::qkvf_*)
+    const unsigned short* w_hi[2]; const unsigned short* w_lo[2];     // Wq | Wk | Wv stacked [3 C][C], fragment-major (DeepWeights::qkvf_*)
     const float* bias[2][3];                                          // q, k, v bias or nullptr
-    unsigned short* out[2][3];                                        // fp16 [M][384] each
+    unsigned short* out[2][3];                                        // fp16 [M][C] each
     float qscale; int cross, M;                                       // cross: K and V of stream s read stream 1 - s
+    int C;                                                            // 384, or 192 (16x16-window levels: the fused Q/K/V + attention kernel covers the rest)
 };
 bool deep_qkv_supported(const swf_block_desc& d);
 int launch_deep_qkv(const DeepQkvArgs& q, int nstream, hipStream_t stream);
+
+// Output projection of a deep block (C = heads * head_dim = 192 or 384) on the same kernel: attention output planes [M][C] in,
+// out = res + bias + O . Wp^T as fp32 rows.  Replaces the projection launch_gemm_sp where attn_proj_kernel / the folded projection do not apply.
+struct DeepProjArgs {
+    const unsigned short* o_hi[2]; const unsigned short* o_lo[2];    // attention output planes (bf16 hi / lo)
+    const unsigned short* w_hi[2]; const unsigned short* w_lo[2];    // Wproj, fragment-major (DeepWeights::pf_*)
+    const float* bias[2]; const float* res[2]; float* out[2];        // bias [C] or nullptr; residual rows; result rows (may alias res)
+    int M, C;
+};
+bool deep_proj_supported(const swf_block_desc& d);
+int launch_deep_proj(const DeepProjArgs& q, int nstream, hipStream_t stream);
 
 }  // namespace swf

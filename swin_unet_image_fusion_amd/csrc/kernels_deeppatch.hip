@@ -15,6 +15,7 @@
 
 #include <cstdlib>
 
+#include "kernels_qkvattn.h"
 #include "win_frag.h"
 
 namespace swf {
@@ -55,8 +56,11 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
     // DEC == 2 (Q/K/V projections of a level-4 block, raw form): the rows are the LayerNorm planes [M][K] (already split bf16), the
     // NTOT = 3 K weight rows are Wq | Wk | Wv stacked, and the epilogue writes (acc + bias) [* d^-0.5 log2 e for Q] as fp16 — the
     // operand formats of attn_proj_kernel (SP_EPI_QKV16 of the GEMM this replaces).  K and V of a cross block read the other stream.
-    constexpr bool RAW = NTOT != N, IS_DEC = DEC == 1, IS_QKV = DEC == 2;
-    static_assert(!IS_QKV || (RAW && NTOT == 3 * K && K % N == 0 && K <= 384), "Q/K/V mode");
+    // DEC == 3 (output projection of a deep block): rows = the attention output planes [M][K], weights = Wproj fragment-major,
+    // epilogue = + bias + residual rows -> out [M][NTOT] (columns [N z, N z + N) per workgroup).
+    constexpr bool IS_DEC = DEC == 1, IS_QKV = DEC == 2, IS_PROJ = DEC == 3, RAW = NTOT != N || IS_PROJ;
+    static_assert(!IS_QKV || (NTOT == 3 * K && K % N == 0 && K <= 384), "Q/K/V mode");
+    static_assert(!IS_PROJ || (NTOT == K && K <= 384), "projection mode");
     constexpr int NT = 64 * NW, MR = 32 * MT, TPR = NT / MR;           // threads, token rows per workgroup, threads per row
     constexpr int KC = K > 384 ? 384 : K, NKC = K / KC, KS = KC / 16;   // columns staged at once, passes, k16 steps per pass
     constexpr int T = N / 32, NF = T / NW, R = T % NW;                  // 32-column tiles; whole tiles per wave; left-over tiles
@@ -98,14 +102,14 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
     const int m = min(tile * MR + row, a.M - 1);   // rows past M are computed on a clamped copy and never stored
     int rb = 0, ry = 0, rx = 0;                     // batch index and position of the row's token in its (merged) map
     if (IS_DEC) { rx = m % a.Wm; const int t = m / a.Wm; ry = t % a.Hm; rb = t / a.Hm; }
-    else if (!IS_QKV) { rx = m % a.Wo; const int t = m / a.Wo; ry = t % a.Ho; rb = t / a.Ho; }
+    else if (!IS_QKV && !IS_PROJ) { rx = m % a.Wo; const int t = m / a.Wo; ry = t % a.Ho; rb = t / a.Ho; }
     const int which = IS_QKV ? (32 * ct0) / K : 0;   // 0 = Q, 1 = K, 2 = V
     constexpr int NV = KC / (4 * TPR);
     static_assert(KC % (4 * TPR) == 0, "row chunks must divide over the row's threads");
     auto stage = [&](int kc) {   // K chunk kc of the rows -> split-bf16 LDS image
-        if constexpr (IS_QKV) {   // the planes are copied as they are: 16-byte chunks of 8 bf16
+        if constexpr (IS_QKV || IS_PROJ) {   // the planes are copied as they are: 16-byte chunks of 8 bf16
             constexpr int NQ = KC / (8 * TPR);
-            const int ss = (which != 0 && a.cross) ? 1 - s : s;
+            const int ss = (IS_QKV && which != 0 && a.cross) ? 1 - s : s;
             const bf16* ph = a.xh[ss] + (size_t)m * K;
             const bf16* pl = a.xl[ss] + (size_t)m * K;
             u32x4 vh[NQ], vl[NQ];
@@ -267,6 +271,20 @@ __global__ __launch_bounds__(64 * NW) void deep_patch_kernel(DpArgs a) {
             bt[i] = *reinterpret_cast<const f32x4*>(a.beta[s] + c);
         }
         sum += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+    }
+    if constexpr (IS_PROJ) {
+        if (live) {
+            const size_t ro = (size_t)m * NTOT + 32 * ct0;
+#pragma unroll
+            for (int i = 0; i < NO; ++i) {
+                const int c = 4 * (sub + TPR * i);
+                f32x4 o = v[i];
+                if (a.skip[s]) o += *reinterpret_cast<const f32x4*>(a.skip[s] + ro + c);   // residual rows (may alias out: same thread, same element)
+                *reinterpret_cast<f32x4*>(a.out[s] + ro + c) = o;
+            }
+        }
+        DP_STAMP(10);
+        return;
     }
     if constexpr (IS_QKV) {
         if (live) {
@@ -563,7 +581,29 @@ int launch_deep_patch_finish(const PatchFusedDesc& d, float* const* raw, int nst
 
 bool deep_qkv_supported(const swf_block_desc& d) {
     static const bool off = std::getenv("SWF_NO_DEEP_QKV") != nullptr;   // A/B switch (tools)
-    return !off && d.precision == SWF_PREC_FAST && d.attn.channels == 384 && d.attn.heads * d.attn.head_dim == 384;
+    const int C = d.attn.channels;
+    // C = 192 only where the fused Q/K/V + attention kernel does not cover the block (16x16 windows)
+    return !off && d.precision == SWF_PREC_FAST && d.attn.heads * d.attn.head_dim == C && (C == 384 || (C == 192 && !qkvattn_supported(d)));
+}
+
+bool deep_proj_supported(const swf_block_desc& d) {
+    static const bool off = std::getenv("SWF_NO_DEEP_PROJ") != nullptr;   // A/B switch (tools)
+    const int C = d.attn.channels;
+    return !off && d.precision == SWF_PREC_FAST && d.attn.heads * d.attn.head_dim == C && (C == 384 || C == 192);
+}
+
+int launch_deep_proj(const DeepProjArgs& q, int nstream, hipStream_t stream) {
+    if (q.M <= 0 || q.M > INT32_MAX / 2048) return fail(SWF_ERR_UNSUPPORTED, "deep_proj: token count");
+    if (q.C != 192 && q.C != 384) return fail(SWF_ERR_UNSUPPORTED, "deep_proj: C=%d", q.C);
+    DpArgs a{};
+    for (int s = 0; s < nstream; ++s) {
+        if (!q.o_hi[s] || !q.o_lo[s] || !q.w_hi[s] || !q.w_lo[s] || !q.out[s]) return fail(SWF_ERR_NULL, "deep_proj: NULL operand (stream %d)", s);
+        a.xh[s] = reinterpret_cast<const bf16*>(q.o_hi[s]); a.xl[s] = reinterpret_cast<const bf16*>(q.o_lo[s]);
+        a.w_hi[s] = reinterpret_cast<const bf16*>(q.w_hi[s]); a.w_lo[s] = reinterpret_cast<const bf16*>(q.w_lo[s]);
+        a.bias[s] = q.bias[s]; a.skip[s] = q.res[s]; a.out[s] = q.out[s];
+    }
+    a.M = q.M;
+    return q.C == 192 ? launch_t<192, 192, 2, 4, 3, 192>(a, nstream, stream) : launch_t<384, 192, 2, 4, 3, 384>(a, nstream, stream);
 }
 
 int launch_deep_qkv(const DeepQkvArgs& q, int nstream, hipStream_t stream) {
@@ -579,6 +619,8 @@ int launch_deep_qkv(const DeepQkvArgs& q, int nstream, hipStream_t stream) {
         }
     }
     a.M = q.M; a.qscale = q.qscale; a.cross = q.cross && nstream == 2;
+    if (q.C == 192) return launch_t<192, 192, 2, 4, 2, 576>(a, nstream, stream);
+    if (q.C != 384) return fail(SWF_ERR_UNSUPPORTED, "deep_qkv: C=%d", q.C);
     return launch_t<384, 192, 2, 4, 2, 1152>(a, nstream, stream);
 }
 

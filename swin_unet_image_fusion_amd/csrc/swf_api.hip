@@ -337,7 +337,7 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
             dq.bias[s][0] = pp[s]->attn.q.bias; dq.bias[s][1] = pp[s]->attn.k.bias; dq.bias[s][2] = pp[s]->attn.v.bias;
             for (int i = 0; i < 3; ++i) dq.out[s][i] = qkv[s][i];
         }
-        dq.qscale = gq.qscale; dq.cross = cross; dq.M = (int)N;
+        dq.qscale = gq.qscale; dq.cross = cross; dq.M = (int)N; dq.C = C;
         SWF_TRY(launch_deep_qkv(dq, nstream, stream));
     }
     if (!fused_attn && !deep_qkv) SWF_TRY(launch_gemm_sp(gq, 3 * nstream, (int)N, HD, C, HD, SP_EPI_QKV16, stream));
@@ -369,7 +369,17 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
     gp.scratch = sk; gp.scratch_floats = sk_floats;
     for (int s = 0; s < nstream; ++s)
         gp.p[s] = SpGemmProb{o_hi[s], o_lo[s], wv[s].p_hi, wv[s].p_lo, pp[s]->attn.proj.bias, xin[s], xout[s], nullptr, nullptr};
-    if (!fold_proj && !attn_proj) SWF_TRY(launch_gemm_sp(gp, nstream, (int)N, C, HD, C, SP_EPI_F32, stream));
+    const bool deep_proj = !fold_proj && !attn_proj && HD == C && deep_proj_supported(*desc) && wv[0].pf_hi && (nstream == 1 || wv[1].pf_hi);
+    if (deep_proj) {   // rows x fragment-major Wproj (+ bias + residual) instead of the plane GEMM
+        DeepProjArgs dp{};
+        for (int s = 0; s < nstream; ++s) {
+            dp.o_hi[s] = o_hi[s]; dp.o_lo[s] = o_lo[s]; dp.w_hi[s] = wv[s].pf_hi; dp.w_lo[s] = wv[s].pf_lo;
+            dp.bias[s] = pp[s]->attn.proj.bias; dp.res[s] = xin[s]; dp.out[s] = xout[s];
+        }
+        dp.M = (int)N; dp.C = C;
+        SWF_TRY(launch_deep_proj(dp, nstream, stream));
+    }
+    if (!fold_proj && !attn_proj && !deep_proj) SWF_TRY(launch_gemm_sp(gp, nstream, (int)N, C, HD, C, SP_EPI_F32, stream));
     // MLP half (a004:29-38 around a003:46-50)
     if (fused_mlp) {   // LN2 + fc1 + ELU + fc2 + residual in one launch (+ a fixed-order reduce over the hidden splits)
         MlpFusedDesc md{};
