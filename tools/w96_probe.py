@@ -1,4 +1,11 @@
-"""Phase stamps of workgroup 0 / wave 0 of window96x8_kernel (diagnostic library built with -DW96_PROBE, loaded through SWF_LIB_PATH)."""
+"""Phase stamps of workgroup 0 / wave 0 of window96x8_kernel (diagnostic library built with -DW96_PROBE, loaded through SWF_LIB_PATH).
+
+    python -c "import __graft_entry__ as g; g.build()"            # objects under swin_unet_image_fusion_amd/csrc/build/
+    hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -DW96_PROBE -c swin_unet_image_fusion_amd/csrc/kernels_win96.hip -o /tmp/w96p.o
+    hipcc -shared -fPIC --offload-arch=gfx950 -o swin_unet_image_fusion_amd/libswf_probe96.so \
+          $(ls swin_unet_image_fusion_amd/csrc/build/*.o | grep -v kernels_win96) /tmp/w96p.o
+    [W96_BATCH=32] SWF_LIB_PATH=$PWD/swin_unet_image_fusion_amd/libswf_probe96.so python tools/w96_probe.py
+"""
 import ctypes as C, os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
