@@ -302,7 +302,7 @@ def test_reference_checkpoint_to_gpu_forward(tmp_path):
     ir, vis = (torch.from_numpy(a) for a in synthetic_pair(2, 128, 128, seed_ir=21, seed_vis=22))
     ref = O.model_forward(sd, cfg, ir, vis)
     # These stress weights (seed 17) put a patch of ill-conditioned tokens at (b=0, y 45..50, x 64..74): the exact tier's own
-    # largest errors sit on the same pixels, 60x its median error (tools/diag_ckpt.py: fp32 tier median 1.7e-7 / max 1.0e-5,
+    # largest errors sit on the same pixels, 60x its median error (tests/diag_ckpt.py: fp32 tier median 1.7e-7 / max 1.0e-5,
     # fast tier median 2.8e-5 / max 1.6e-3, rel-L2 1.5e-4).  The max-error gate of this one case is therefore 5e-3; the
     # rel-L2 gate stays at the north-star 1e-3.
     for precision, tol in (("fp32", (5e-5, None)), ("fast", (TOL_FAST_L2, 5e-3))):
