@@ -45,6 +45,10 @@ def parse():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs per CPU-baseline forward")
     ap.add_argument("--cpu-iters", type=int, default=3)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="rehearse the control flow (process group, barriers, pipelined step_async, MAX all-reduce of the elapsed time, rank-0 "
+                         "JSON) on CPU tensors over gloo with a stub forward: no GPU, no library, no number worth reading (tests/test_bench_dryrun.py)")
+    ap.add_argument("--no-levels", action="store_true", help="skip the per-level roofline pass (swf_model_forward_profiled)")
     return ap.parse_args()
 
 
@@ -120,6 +124,110 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
             "ms_per_launch": round(ms, 4), "algorithmic_bytes": alg_bytes, "bytes_per_elem": BYTES_PER_ELEM}
 
 
+MFMA_PEAK_FLOPS = 2.5e15    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak
+# kernel symbols of one BasicBlock per level at the default dims with 8x8 / 7x7 windows on 256x256 inputs;
+# other shapes dispatch differently (profiles/*_forward_timeline*.txt name what ran)
+LEVEL_KERNELS_WIN8 = {
+    0: "window24_kernel<HID, WS>", 1: "window48_kernel<HID, WS>", 2: "window96x8_kernel<HID, WS> (maps of > 16 windows: window96_kernel)",
+    3: "qkv_attn_kernel<192, WS> + mlp_fused_kernel<192, 4> (+ mlp_reduce_ln_kernel when the hidden dim is split)",
+    4: "deep_patch_kernel<384, 192, .., 1152> (Q/K/V) + attn_proj_kernel<WS> + mlp_fused_kernel<384, 8> + mlp_reduce_ln_kernel",
+}
+
+
+def level_rooflines(model, ir, vis, step_ms, iters=5):
+    """Per level: HIP-event time of the four BasicBlocks of the stage INSIDE one eager forward (swf_model_forward_profiled: events on
+    the launch stream between the stages), algorithmic bytes and flops of one block, and the fractions of the HBM and dense-MFMA
+    peaks they amount to.  Algorithmic bytes per block (both streams, e = 4): 4*N*C*e + fp32 weights.  Algorithmic flops
+    per block: per stream QKV 6NC^2 + proj 2NC^2 + QK^T 2NtC + P.V 2NtC + MLP 4NC*hid.  The linears run as three
+    bf16 MFMAs per product (split-bf16), so the MFMA pipe executes ~3x the linear flops counted here: `frac_mfma` is algorithmic."""
+    from swin_unet_image_fusion_amd import _lib as L
+    from swin_unet_image_fusion_amd.modules import _ptr, _stream, _workspace
+    lib, desc = L.lib(), model._model_desc()
+    if desc.precision != L.PREC_FAST:
+        return None
+    b, _, h, w = ir.shape
+    dev = ir.device
+    arena = model._get_arena(dev)
+    packed = model._get_packed(arena)
+    out = torch.empty((b, 1, h, w), dtype=torch.float32, device=dev)
+    ws, wsn = _workspace(lib.swf_model_workspace_bytes(C.byref(desc), b, h, w), dev)
+    n = len(model.in_dims_list)
+    nseg = 4 * n + 1
+    seg = (C.c_float * nseg)()
+    acc = [0.0] * nseg
+    for it in range(iters + 1):
+        L.check(lib.swf_model_forward_profiled(C.byref(desc), _ptr(arena), packed.data_ptr(), _ptr(ir), _ptr(vis), _ptr(out), b, h, w,
+                                               ws, wsn, seg, nseg, _stream(dev)))
+        if it:   # the first pass warms caches and clocks
+            acc = [a + float(v) for a, v in zip(acc, seg)]
+    ms = [a / iters for a in acc]
+    wh, ww = model.window_size
+    mh, mw = model.merging_size
+    t = wh * ww
+    tbl = (2 * wh - 1) * (2 * ww - 1)
+    levels, patches = [], []
+    total_bytes = 0
+    hh, wd = h, w
+    shapes = []
+    for s in range(n):   # map of level s: merged (reflect-padded to the merge size), then padded to a multiple of the window
+        hm, wm = -(-hh // mh), -(-wd // mw)
+        ho, wo = -(-hm // wh) * wh, -(-wm // ww) * ww
+        shapes.append((hh, wd, hm, wm, ho, wo))
+        hh, wd = ho, wo
+    for side in ("encoder", "decoder"):
+        for k in range(n):
+            lvl = k if side == "encoder" else n - 1 - k
+            c = model.out_dims_list[lvl]
+            hid = (model.out_dims_list[lvl] if side == "encoder" else model.in_dims_list[lvl]) * model.mlp_hidden_dims_ratio
+            hd = model.att_num_heads * int(model.out_dims_list[lvl] * model.att_dims_per_head_ratio)
+            hin, win, hm, wm, ho, wo = shapes[lvl]
+            ntok = b * ho * wo
+            wbytes = 2 * (3 * c * hd + 3 * hd + hd * c + c + tbl + 4 * c + 2 * c * hid + hid + c) * 4
+            blk_bytes = 4 * ntok * c * BYTES_PER_ELEM + wbytes
+            blk_flops = 2 * (ntok * (6 * c * hd + 2 * hd * c) + 4 * ntok * t * hd + 4 * ntok * c * hid)
+            lin_flops = 2 * (ntok * (6 * c * hd + 2 * hd * c) + 4 * ntok * c * hid)
+            seg_i = 2 * lvl + 1 if side == "encoder" else 2 * n + 2 * k
+            us = ms[seg_i] * 1e3 / 4
+            entry = {"level": lvl, "side": side, "C": c, "hidden": hid, "tokens_per_stream": ntok, "us_per_block": round(us, 2),
+                     "kernels": LEVEL_KERNELS_WIN8.get(lvl, "see profiles/") if wh in (7, 8) and n == 5 else "see profiles/",
+                     "algorithmic_bytes": blk_bytes, "algorithmic_flops": blk_flops,
+                     "frac_hbm": round(blk_bytes / (us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
+                     "frac_mfma": round(blk_flops / (us * 1e-6) / MFMA_PEAK_FLOPS, 4),
+                     "frac_mfma_issued": round((blk_flops + 2 * lin_flops) / (us * 1e-6) / MFMA_PEAK_FLOPS, 4)}
+            if lvl == 0 and side == "encoder" and c == 24 and hid == 96 and wh == 8:
+                # DESIGN.md section 5 issue model of window24_kernel<96, 8>: per wave and window 1 308 VALU wave-instructions priced by issue
+                # class (tools/valu_rate_bench.hip) = 2.67 us and 124 MFMAs = 1.76 us, serialised on the wave's SIMD; 4 waves per window
+                wave_windows_per_simd = (ntok // t) * 4 / 1024.0
+                model_us = (2.67 + 1.76) * wave_windows_per_simd
+                entry["issue_model_us"] = round(model_us, 1)
+                entry["frac_valu_mfma_issue"] = round(model_us / us, 4)
+                entry["bound"] = "VALU + MFMA issue of the SIMD (exp2 and split-bf16 conversions), not HBM"
+            levels.append(entry)
+            total_bytes += 4 * blk_bytes
+            # the patch layer next to the stage: reads 4*Cin (merge) / Cin (un-merge) and writes Cout / 4*Cout per merged token, + skip
+            cin = model.in_dims_list[lvl]
+            if side == "encoder":
+                pbytes = 2 * (b * hm * wm) * (4 * cin + c) * BYTES_PER_ELEM
+                pus = ms[2 * lvl] * 1e3
+            else:
+                pbytes = 2 * (b * hm * wm) * (c + 4 * cin) * BYTES_PER_ELEM + (2 * (b * hin * win) * cin * BYTES_PER_ELEM if lvl > 0 else 0)
+                pus = ms[2 * n + 2 * k + 1] * 1e3
+            patches.append({"level": lvl, "side": side, "us": round(pus, 2), "algorithmic_bytes": pbytes,
+                            "frac_hbm": round(pbytes / (pus * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)})
+            total_bytes += pbytes
+    head_bytes = 3 * b * h * w * BYTES_PER_ELEM
+    head_us = ms[4 * n] * 1e3
+    total_bytes += head_bytes
+    eager_ms = sum(ms)
+    return {"levels": levels, "patch_layers": patches,
+            "head": {"us": round(head_us, 2), "algorithmic_bytes": head_bytes, "frac_hbm": round(head_bytes / (head_us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4)},
+            "forward": {"algorithmic_bytes": total_bytes, "frac_hbm": round(total_bytes / (step_ms * 1e-3) / (HBM_PEAK_GBS * 1e9), 4),
+                        "ms_per_step": round(step_ms, 4), "eager_profiled_ms": round(eager_ms, 4),
+                        "note": "whole forward: every fused block reads and writes each stream once (e = 4 B) + weights + patch layers + head, "
+                                "divided by the timed step; eager_profiled_ms = sum of the segment events of the per-level pass"},
+            "measured_by": f"swf_model_forward_profiled: HIP events on the launch stream between the stages of one eager forward, mean of {iters}"}
+
+
 def cpu_baseline(cfg, size, pairs, iters):
     """The CPU oracle (port of the reference's PyTorch-CPU forward, pinned to the reference by
     tests/test_oracle_golden.py) on the host cores, bounded sample of the same workload."""
@@ -165,27 +273,39 @@ def main():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    dry = args.dry_run
+    if dry:     # the same control flow on CPU tensors over gloo; nothing below touches a GPU or the library
+        dev = torch.device("cpu")
+        sync = lambda: None
+    else:
+        torch.cuda.set_device(local)
+        dev = torch.device("cuda", local)
+        sync = torch.cuda.synchronize
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)   # RCCL
+        if dry:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)   # RCCL
 
-    import __graft_entry__ as entry
-    if rank == 0:
-        entry.build()
-    if world > 1:
-        dist.barrier()
     from swin_unet_image_fusion_amd import CONFIGS, MyModel, load_recipe_into, synthetic_pair
     from swin_unet_image_fusion_amd.shard import ShardedFusion
-
     cfg = CONFIGS[args.config]
     torch.set_grad_enabled(False)
-    model = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True))).eval()
-    load_recipe_into(model, seed=0, flavor="default")     # random-init weights of the named architecture
-    model.to(dev)
-    model.precision = args.precision
-    runner = ShardedFusion(model, world_size=world, rank=rank, use_graph=not args.no_graph)
+    if dry:
+        model = None
+        runner = ShardedFusion(None, world_size=world, rank=rank, use_graph=False, forward_fn=lambda a, b: 0.5 * (a + b))
+    else:
+        import __graft_entry__ as entry
+        if rank == 0:
+            entry.build()
+        if world > 1:
+            dist.barrier()
+        model = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True))).eval()
+        load_recipe_into(model, seed=0, flavor="default")     # random-init weights of the named architecture
+        model.to(dev)
+        model.precision = args.precision
+        runner = ShardedFusion(model, world_size=world, rank=rank, use_graph=not args.no_graph)
 
     # synthetic IR / visible pairs, distinct per rank, resident in HBM before the timed region
     ir, vis = synthetic_pair(args.batch, args.size, args.size, seed_ir=1 + 2 * rank, seed_vis=2 + 2 * rank)
@@ -193,10 +313,10 @@ def main():
 
     for _ in range(max(args.warmup, 1)):
         fused = runner.step(ir, vis)
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
     # every step = forward of the local shard + all-gather of the fused outputs; the gather of step i runs on RCCL's stream under
     # the forward of step i+1 and is waited for (stream-level) one step later; all K gathers have completed at the final sync
@@ -207,10 +327,10 @@ def main():
             fused = pending.wait()
         pending = handle
     fused = pending.wait()
-    torch.cuda.synchronize()
+    sync()
     if world > 1:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -239,9 +359,18 @@ def main():
                        "collective": "rccl all_gather_into_tensor of the fused output per step, overlapped with the next step's forward" if world > 1 else "none",
                        "weights": "random-init (numpy PCG64 recipe, seed 0)"},
         }
-        line["roofline"] = level0_block_roofline(model, args.batch, args.size, args.precision)
-        if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.cpu_pairs, args.cpu_iters)
+        if dry:
+            line["dry_run"] = True
+            line["data"] = "synthetic; DRY RUN on CPU over gloo with a stub forward: the value measures nothing"
+            line["config"]["collective"] = "gloo all_gather (stub forward)" if world > 1 else "none"
+        else:
+            line["roofline"] = level0_block_roofline(model, args.batch, args.size, args.precision)
+            if not args.no_levels and args.precision == "fast":
+                per_level = level_rooflines(model, ir, vis, elapsed / args.steps * 1e3)
+                if per_level:
+                    line["roofline"].update(per_level)
+            if world == 1 and not args.no_cpu_baseline:
+                line["cpu_baseline"] = cpu_baseline(cfg, args.size, args.cpu_pairs, args.cpu_iters)
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()

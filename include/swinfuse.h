@@ -49,7 +49,7 @@ typedef enum swf_status {
 /* Arithmetic mode of the window-attention contractions and linear layers.
  *  FP32 : every contraction in exact fp32 (f32-input MFMA == fmaf chain; VALU attention).
  *  FAST : fused window kernels — linear layers as split-bf16 (bf16x3, fp32-grade) MFMA,
- *         QK^T in bf16 MFMA, P.V in fp16 MFMA; LayerNorm statistics, softmax, residual
+ *         QK^T in f16 MFMA, P.V in fp16 MFMA; LayerNorm statistics, softmax, residual
  *         stream and all accumulators stay fp32.  Shapes the fused kernels do not cover
  *         fall back to FP32 kernels (never to the host). */
 typedef enum swf_precision { SWF_PREC_FP32 = 0, SWF_PREC_FAST = 1 } swf_precision;
@@ -79,6 +79,12 @@ int swf_window_attention_fwd(const swf_attn_desc* desc, const swf_attn_params* p
                              const float* q, const float* k, const float* v, const float* residual,
                              float* out, int32_t B, int32_t H, int32_t W,
                              void* workspace, size_t workspace_bytes, swf_stream_t stream);
+/* The same with the arithmetic mode as an argument (swf_precision): SWF_PREC_FAST runs the four projections as split-bf16 MFMA
+ * GEMMs and QK^T / P.V on the f16 MFMA attention core (same workspace query); swf_window_attention_fwd == SWF_PREC_FP32. */
+int swf_window_attention_fwd_prec(const swf_attn_desc* desc, int32_t precision, const swf_attn_params* p,
+                                  const float* q, const float* k, const float* v, const float* residual,
+                                  float* out, int32_t B, int32_t H, int32_t W,
+                                  void* workspace, size_t workspace_bytes, swf_stream_t stream);
 size_t swf_window_attention_workspace_bytes(const swf_attn_desc* desc, int32_t B, int32_t H, int32_t W);
 
 /* ---- BasicBlock (a005_BasicBlock.py:127-145) and its two halves ---------------------------- */
@@ -179,6 +185,12 @@ int swf_final_head_fwd(const swf_head_params* p, const float* x, const float* y,
  * nn.Linear (a001:42-61) and 1x1 nn.Conv2d on NHWC tokens (a003:21-22, a011:60-63).  Exact fp32. */
 int swf_linear_fwd(const swf_linear* lin, const float* in, const float* residual, float* out,
                    int64_t tokens, int32_t n_in, int32_t n_out, int32_t act, swf_stream_t stream);
+/* The same with the arithmetic mode as an argument: SWF_PREC_FAST = split-bf16 (bf16x3) MFMA, fp32 accumulate (deterministic
+ * split-K for deep K: workspace from swf_linear_workspace_bytes, 0 for SWF_PREC_FP32). */
+size_t swf_linear_workspace_bytes(int32_t precision, int64_t tokens, int32_t n_in, int32_t n_out);
+int swf_linear_fwd_prec(const swf_linear* lin, int32_t precision, const float* in, const float* residual, float* out,
+                        int64_t tokens, int32_t n_in, int32_t n_out, int32_t act,
+                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
 /* my_layer_norm (a004:54-72): LayerNorm over C of [tokens][C], eps 1e-5; elu != 0 applies ELU after. */
 int swf_layernorm_fwd(const swf_norm* ln, const float* in, float* out, int64_t tokens, int32_t C, int32_t elu,
                       swf_stream_t stream);
@@ -241,6 +253,15 @@ int swf_model_forward_packed(const swf_model_desc* desc, const float* arena, con
 int swf_model_forward_checked(const swf_model_desc* desc, const float* arena, const void* packed,
                               const float* ir, const float* vis, float* out, int32_t B, int32_t H, int32_t W,
                               void* workspace, size_t workspace_bytes, int32_t* cross_equal_flags, swf_stream_t stream);
+/* Measurement entry (bench.py's per-level roofline): swf_model_forward_packed with HIP events recorded on `stream` between
+ * the stages of a013:209-230.  Unlike every other entry it SYNCHRONISES the stream (and so cannot be graph-captured), then
+ * writes the elapsed milliseconds of the 4 * levels + 1 segments to the host array seg_ms: for s = 0 .. levels-1
+ * [2s] = the patch-merging layer of encoder stage s (a011), [2s + 1] = its four BasicBlocks (a012); for j = 0 .. levels-1
+ * [2 levels + 2j] = the four BasicBlocks of decoder stage j (level levels-1-j), [2 levels + 2j + 1] = its un-merging layer (with
+ * the skip add); [4 levels] = the final head (a013:126-152).  seg_count = capacity of seg_ms. */
+int swf_model_forward_profiled(const swf_model_desc* desc, const float* arena, const void* packed,
+                               const float* ir, const float* vis, float* out, int32_t B, int32_t H, int32_t W,
+                               void* workspace, size_t workspace_bytes, float* seg_ms, int32_t seg_count, swf_stream_t stream);
 /* *flag (device int32) = 1 if a[i] == b[i] for every i < count, else 0 (torch semantics: NaN != NaN).  The first-call
  * test of BasicBlock / SelfAndCrossBlockPair (a005:111-113) without a device->host copy of the tensors. */
 int swf_tensors_equal(const float* a, const float* b, int64_t count, int32_t* flag, swf_stream_t stream);

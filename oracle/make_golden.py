@@ -200,6 +200,10 @@ MODEL_CASES = [
     ("model_win8_512_default", "win8", (1, 512, 512), "default"),           # BASELINE config 3 shape, B=1
     ("model_win16_1024_default", "win16", (1, 1024, 1024), "default"),      # BASELINE config 5 shape, B=1
     ("model_win7_224_default", "win7", (1, 224, 224), "default"),           # the reference's default window (A000:55), every map a multiple of 7
+    # the initialisation the reference trains from (a016:42, a016:382-390): kaiming_normal_ weights, zero biases
+    ("model_win8_256_kaiming", "win8", (1, 256, 256), "kaiming"),
+    ("model_win7_224_kaiming", "win7", (1, 224, 224), "kaiming"),
+    ("model_win8_4stage_128_kaiming", "win8_4stage", (2, 128, 128), "kaiming"),
 ]
 
 

@@ -73,6 +73,7 @@ SIGNATURES = {
     "swf_last_error_string": (C.c_char_p, []),
     "swf_status_string": (C.c_char_p, [C.c_int]),
     "swf_window_attention_fwd": (C.c_int, [P(AttnDesc), P(AttnParams), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_window_attention_fwd_prec": (C.c_int, [P(AttnDesc), _i32, P(AttnParams), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_window_attention_workspace_bytes": (_sz, [P(AttnDesc), _i32, _i32, _i32]),
     "swf_attn_halfblock_fwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_mlp_halfblock_fwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
@@ -88,6 +89,8 @@ SIGNATURES = {
     "swf_patch_workspace_bytes": (_sz, [_i32] * 10),
     "swf_final_head_fwd": (C.c_int, [P(HeadParams), _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_linear_fwd": (C.c_int, [P(Linear), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "swf_linear_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
+    "swf_linear_fwd_prec": (C.c_int, [P(Linear), _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_layernorm_fwd": (C.c_int, [P(Norm), _vp, _vp, _i64, _i32, _i32, _vp]),
     "swf_reflect_pad_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "swf_crop_fwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
@@ -105,6 +108,7 @@ SIGNATURES = {
     "swf_model_pack_weights": (C.c_int, [P(ModelDesc), _vp, _vp, _sz, _vp]),
     "swf_model_forward_packed": (C.c_int, [P(ModelDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_model_forward_checked": (C.c_int, [P(ModelDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp, _vp]),
+    "swf_model_forward_profiled": (C.c_int, [P(ModelDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, P(C.c_float), _i32, _vp]),
     "swf_tensors_equal": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
 }
 

@@ -102,7 +102,9 @@ def _draw(rng: np.random.Generator, key: str, shape: Tuple[int, ...], flavor: st
     """One tensor of the recipe.  `default` follows the reference constructors' distributions
     (nn.Linear / nn.Conv2d U(+-1/sqrt(fan_in)), LayerNorm 1/0, bias table N(0,1) a001:76,
     BatchNorm 1/0/0/1).  `stress` perturbs every affine / statistic so that a kernel that
-    drops one of them cannot pass parity."""
+    drops one of them cannot pass parity.  `kaiming` is what the reference TRAINS from
+    (a016_train.py:42 applies init_params, a016:382-390: `init.kaiming_normal_` = N(0, 2/fan_in) on every
+    Linear / Conv2d weight, zero biases; norms and bias tables keep their constructor values)."""
     leaf = key.rsplit(".", 1)[-1]
     if leaf == "num_batches_tracked":
         return np.zeros(shape, dtype=np.int64)
@@ -112,7 +114,7 @@ def _draw(rng: np.random.Generator, key: str, shape: Tuple[int, ...], flavor: st
         return rng.standard_normal(shape).astype(np.float32)
     is_norm = ("norm_layer_" in key) or ("layer_norm_" in key) or key.startswith("final_layer.1.")
     if is_norm:
-        if flavor == "default":
+        if flavor in ("default", "kaiming"):
             if leaf in ("weight", "running_var"):
                 return np.ones(shape, dtype=np.float32)
             return np.zeros(shape, dtype=np.float32)
@@ -129,7 +131,7 @@ def _draw(rng: np.random.Generator, key: str, shape: Tuple[int, ...], flavor: st
 def make_state_arrays(shapes_by_key: Dict[str, Tuple[int, ...]], alias_of: Dict[str, str],
                       seed: int = 0, flavor: str = "default") -> Dict[str, np.ndarray]:
     """Draw every unique tensor; returns arrays for *all* keys (aliases share the array)."""
-    assert flavor in ("default", "stress")
+    assert flavor in ("default", "stress", "kaiming")
     rng = np.random.default_rng(np.random.PCG64(seed))
     canon = _canonical_groups(shapes_by_key, alias_of)
     drawn: Dict[str, np.ndarray] = {}
@@ -144,6 +146,13 @@ def make_state_arrays(shapes_by_key: Dict[str, Tuple[int, ...]], alias_of: Dict[
         try:
             drawn[key] = _draw(rng, key, shape, flavor)
         except KeyError:
+            if flavor == "kaiming":   # a016:382-390
+                leaf = key.rsplit(".", 1)[-1]
+                if leaf == "bias":
+                    drawn[key] = np.zeros(shape, dtype=np.float32)
+                else:
+                    drawn[key] = (rng.standard_normal(shape) * math.sqrt(2.0 / fan_in_for(key))).astype(np.float32)
+                continue
             bound = gain / math.sqrt(fan_in_for(key))
             drawn[key] = rng.uniform(-bound, bound, shape).astype(np.float32)
     return {k: drawn[alias_of.get(k, k)] for k in shapes_by_key}

@@ -272,7 +272,7 @@ __global__ __launch_bounds__(512) void attn_proj_kernel(ApDev a) {
 }  // namespace
 
 bool attnproj_supported(const swf_block_desc& d) {
-    static const bool off = std::getenv("SWF_NO_ATTNPROJ") != nullptr;   // A/B switch (tools)
+    static const bool off = debug_env("SWF_NO_ATTNPROJ") != nullptr;   // A/B switch (tools)
     return !off && d.precision == SWF_PREC_FAST && d.attn.channels == kC && d.attn.heads == kHeads && d.attn.head_dim == kD &&
            d.attn.win_h == d.attn.win_w && (d.attn.win_h == 8 || d.attn.win_h == 7);
 }

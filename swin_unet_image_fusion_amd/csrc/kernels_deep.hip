@@ -324,7 +324,7 @@ int launch_gemm_sp(const SpGemmBatch& batch, int nprob, int M, int N, int K, int
     if (count(128, 128) >= fill && N % 128 == 0) cfg = 0;
     else if (count(128, 64) >= fill) cfg = 1;
     else cfg = 2;
-    static const int forced_cfg = [] { const char* e = std::getenv("SWF_SP_CFG"); return e ? e[0] - '0' : -1; }();   // tools/gemm_bench.hip
+    static const int forced_cfg = [] { const char* e = debug_env("SWF_SP_CFG"); return e ? e[0] - '0' : -1; }();   // tools/gemm_bench.hip
     if (forced_cfg >= 0 && forced_cfg <= 2) cfg = forced_cfg;
     if (cfg == 0) {
         dim3 grid(cdiv(M, 128), cdiv(N, 128), nprob * splitk);

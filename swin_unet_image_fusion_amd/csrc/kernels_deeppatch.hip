@@ -538,7 +538,7 @@ struct Shape { int dec, K, N, raw; };   // raw: conv + bias only (column slices 
 constexpr Shape kShapes[] = {{0, 384, 192, 0}, {0, 768, 384, 1}, {1, 384, 768, 1}, {1, 192, 384, 0}};
 
 int shape_index(int decoder, int Cin, int Cout, int mh, int mw) {
-    static const bool off = std::getenv("SWF_NO_DEEP_PATCH") != nullptr;   // A/B switch (tools)
+    static const bool off = debug_env("SWF_NO_DEEP_PATCH") != nullptr;   // A/B switch (tools)
     if (off || mh != 2 || mw != 2 || Cin % 4 || Cout % 4) return -1;
     const int K = decoder ? Cin : 4 * Cin, N = decoder ? 4 * Cout : Cout;
     for (int i = 0; i < 4; ++i)
@@ -580,14 +580,14 @@ int launch_deep_patch_finish(const PatchFusedDesc& d, float* const* raw, int nst
 }
 
 bool deep_qkv_supported(const swf_block_desc& d) {
-    static const bool off = std::getenv("SWF_NO_DEEP_QKV") != nullptr;   // A/B switch (tools)
+    static const bool off = debug_env("SWF_NO_DEEP_QKV") != nullptr;   // A/B switch (tools)
     const int C = d.attn.channels;
     // C = 192 only where the fused Q/K/V + attention kernel does not cover the block (16x16 windows)
     return !off && d.precision == SWF_PREC_FAST && d.attn.heads * d.attn.head_dim == C && (C == 384 || (C == 192 && !qkvattn_supported(d)));
 }
 
 bool deep_proj_supported(const swf_block_desc& d) {
-    static const bool off = std::getenv("SWF_NO_DEEP_PROJ") != nullptr;   // A/B switch (tools)
+    static const bool off = debug_env("SWF_NO_DEEP_PROJ") != nullptr;   // A/B switch (tools)
     const int C = d.attn.channels;
     return !off && d.precision == SWF_PREC_FAST && d.attn.heads * d.attn.head_dim == C && (C == 384 || C == 192);
 }

@@ -530,7 +530,7 @@ int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
 
 // 8 waves on one 256-wide hidden chunk per workgroup (C = 384; SWF_MLP8=0: the 4-wave kernel, tools only)
 static bool mlp_wide(int C, int HID) {
-    static const bool off = [] { const char* e = std::getenv("SWF_MLP8"); return e && e[0] == '0'; }();
+    static const bool off = [] { const char* e = debug_env("SWF_MLP8"); return e && e[0] == '0'; }();
     return !off && C == 384 && HID % 256 == 0;
 }
 
@@ -540,7 +540,7 @@ bool mlp_fused_supported(int C, int HID) {
 
 // hidden splits as a function of the layer shape alone: about two 128-wide chunks per workgroup
 int mlp_fused_splits(int C, int HID) {
-    static const int forced = [] { const char* e = std::getenv("SWF_MLP_SPLITS"); return e ? atoi(e) : 0; }();   // tools: tuning override
+    static const int forced = [] { const char* e = debug_env("SWF_MLP_SPLITS"); return e ? atoi(e) : 0; }();   // tools: tuning override
     if (mlp_wide(C, HID)) return HID / 256;
     if (forced > 0 && (HID / 128) % forced == 0) return forced;
     const int chunks = HID / 128;

@@ -1215,7 +1215,7 @@ int launch_win96(const swf_block_desc& d, const void* packed_x, const void* pack
         else hipLaunchKernelGGL((window96w16_kernel<192>), dim3(gx, 2), dim3(256), G96<192>::l_total16, stream, a);
         return check_launch("window96w16");
     }
-    static const bool no_x8 = [] { const char* e = std::getenv("SWF_WIN96X8"); return e && e[0] == '0'; }();   // A/B switch (tools)
+    static const bool no_x8 = [] { const char* e = debug_env("SWF_WIN96X8"); return e && e[0] == '0'; }();   // A/B switch (tools)
     // Maps of up to 16 windows (32 x 32 tokens: B=16 256x256 has 256 windows for 256 CUs) take eight waves per window
     // (window96x8_kernel).  The rule looks at the map, never at the batch: batch shards stay bit-identical.
     if (!no_x8 && (H / wsd) * (W / wsd) <= 16) {

@@ -2,8 +2,7 @@
 //   * the dispatcher of the fused BasicBlock launch (a005:127-145, both streams): window_block_supported / packed_bytes /
 //     pack_window_block / launch_window_block route C = 24, 48, 96 to the register-resident kernels of kernels_win24.hip,
 //     kernels_win48.hip, kernels_win96.hip (8x8, 7x7 and 16x16 windows);
-//   * window_block_kernel<C, HID, TT>, the round-1 design those kernels replaced (activations as split-bf16 LDS images, one
-//     workgroup per CU at C = 96): kept as the A/B fallback behind SWF_WIN24=0 / SWF_WIN48=0 / SWF_WIN96=0 (8x8 and 7x7 windows);
+//     (the round-1 LDS-image block kernel those replaced is gone; DESIGN.md Appendix A keeps its measurements);
 //   * the stand-alone MFMA attention cores on projection buffers: attn_core_mfma_kernel<D, WS> (8x8 / 7x7 windows: the deep
 //     levels' core) and attn_core_mfma16_kernel<D> (16x16 windows, online softmax over key tiles), both with optional 16-bit
 //     operand inputs and split-plane output for the deep-level GEMM path (kernels_deep.hip);
@@ -19,11 +18,6 @@
 //   LayerNorm statistics, bias, mask, softmax, ELU, residual stream, accumulators: fp32.
 //   exp() runs as v_exp_f32 (exp2): Wq/bq carry d^-0.5*log2(e), the bias matrices carry log2(e).
 //
-// window_block_kernel in short: persistent workgroups walk the windows; a wave keeps its token rows for every per-token phase
-// (LN1, Q/K/V, proj, LN2, MLP) with the residual rows in registers in the MFMA output layout; only attention mixes tokens
-// (two workgroup barriers per window); weights stream from L2, every fragment feeding two MFMAs at TT = 2 (32 tokens per
-// wave); every launch ends by touching the next block's packed weights (per-XCD L2 warm-up).  The SWF_* macros below select
-// the layouts that shipped in round 1 (their alternatives are the measured-and-rejected variants of DESIGN.md Appendix A).
 #include "kernels_window.h"
 #include "kernels_win24.h"
 #include "kernels_win48.h"
@@ -32,37 +26,6 @@
 #include <algorithm>
 #include <cstdlib>
 #include <mutex>
-
-#ifndef SWF_HEAD_UNROLL_C24
-#define SWF_HEAD_UNROLL_C24 2
-#endif
-#ifndef SWF_MLP_ROTATE
-#define SWF_MLP_ROTATE 1
-#endif
-#ifndef SWF_C96_TT2
-#define SWF_C96_TT2 1   // C = 96 block kernel: 4 waves x 32 tokens, one wave per SIMD (106 -> 98 us, 79 -> 74 us)
-#endif
-#ifndef SWF_C24_L2
-#define SWF_C24_L2 1    // C = 24 (level 0): weights from L2 instead of LDS, 4 waves x 32 tokens, three 51-KB workgroups per CU = 3 waves
-                        // per SIMD at 168 registers (the 32 bias registers are reloaded per window so they are dead outside the
-                        // attention phase).  hidden 96: 133 -> 124 us, hidden 4: 108 -> 96 us per block.  Level 0 was short of
-                        // independent waves (VALU busy 50 %, waves waiting 43 %), not of LDS bandwidth.
-#endif
-#ifndef SWF_C48_TWO_WG
-#define SWF_C48_TWO_WG 1   // C = 48: no separate Q image (Q rows live in the wave's own, by then dead, A-lo rows) -> 74 KB tile, two
-                           // workgroups per CU = 2 waves per SIMD at 256 registers, instead of one 512-register workgroup with the
-                           // rotating MLP prefetch
-#endif
-#ifndef SWF_C48_TT2
-#define SWF_C48_TT2 1   // C = 48 block kernel: 32 tokens per wave (see window_block_kernel)
-#endif
-
-#ifdef SWF_WIN_PROBE   // tools/win_probe.hip: wall-clock stamps (10 ns ticks) of workgroup SWF_WIN_PROBE, thread 0, first window
-__device__ unsigned long long swf_win_probe[16];
-#define SWF_WPROBE(i) do { if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0 && win == (int)blockIdx.x) swf_win_probe[i] = wall_clock64(); } while (0)
-#else
-#define SWF_WPROBE(i) do { } while (0)
-#endif
 
 namespace swf {
 
@@ -77,83 +40,6 @@ constexpr float kLog2e = 1.4426950408889634f;
 constexpr int cceil(int a, int b) { return (a + b - 1) / b; }
 constexpr int cround(int a, int b) { return cceil(a, b) * b; }
 constexpr size_t cmax(size_t a, size_t b) { return a > b ? a : b; }
-
-// ------------------------------------------------------------------------------------------
-// geometry shared by the pack kernel, the block kernel and the host
-// ------------------------------------------------------------------------------------------
-template <int C_, int HID_>
-struct Geo {
-    static constexpr int C = C_, HID = HID_, T = 64, WH = 8, WW = 8, HEADS = 8, D = C / 8;
-    // Are both streams' weight sections LDS-resident?  They are at C=24 (2 x 35 KB).  From C=48 on they do not fit
-    // next to the window tile (2 x 135 KB); the kernel then reads weight fragments from L2 (all workgroups share
-    // the same lines; a wave's fragment loads are address-independent and issue ahead of their MFMAs).
-    static constexpr bool SMALL_L2 = C == 24 && SWF_C24_L2;   // see SWF_C24_L2
-    static constexpr bool WLDS = C <= 24 && !SMALL_L2;
-    static constexpr int NTK = cround(C, 32) / 16;                       // 16-wide tiles spanning the padded row (residual registers per lane = 4 * NTK)
-    static_assert(C % 8 == 0, "8 heads of C/8 channels");
-    static constexpr int KC = cround(C, 32), KH = cround(HID, 32);      // K extents padded to the MFMA k-step
-    // row stride (bf16) of the packed fc2 weights: read from L2 (C >= 48) the rows are padded by 16 B (no two rows of a
-    // fragment start on the same 128-byte line offset); LDS-resident (C = 24) they keep KH and are chunk-swizzled (WSWZ below)
-    static constexpr int LDW2 = (WLDS && cround(C, 32) == 32) ? KH : KH + 8;   // swizzled instead of padded when LDS-resident (WSWZ)
-    // LDS-resident K-major weights with 64-byte rows (C = 24): a plain 16-row fragment read is 2-way conflicted in every
-    // ds_read_b128 lane group ({0-3,12-15,20-27}, ...: rows r and r+4.. share a 64-byte bank quarter).  The pack stores the
-    // 16-byte chunk g of row n at position g ^ wswz(n), which makes all four groups conflict-free (wswz below).
-    static constexpr bool WSWZ = WLDS && KC == 32;
-    static constexpr int LDC = KC + 8;                                  // row stride (bf16) of the token-major images: odd multiple of 16 B -> conflict-free b128 reads
-    static constexpr int NTC = cceil(C, 16), NTH = cceil(HID, 16);      // 16-wide output tiles
-    static constexpr int NH = NTH * 16;
-    static constexpr int NKS = KC / 16;                                 // 16-deep k-steps spanning all channels (Q.K^T walks only those a head touches)
-    static constexpr int MT = cceil(D, 32);                             // 32-row M tiles of O^T per head
-    static constexpr int VRS = T + 8;                                   // V^T row stride (halves; 144 B keeps b128 alignment and spreads rows over banks)
-
-    // ---- packed weights of one stream.  The first `wsec` bytes are staged verbatim into LDS. ----
-    static constexpr size_t p_wqkv_hi = 0, p_wqkv_lo = p_wqkv_hi + size_t(3) * C * KC * 2;     // [3C][KC] bf16 (Wq pre-scaled)
-    static constexpr size_t p_wp_hi = p_wqkv_lo + size_t(3) * C * KC * 2, p_wp_lo = p_wp_hi + size_t(C) * KC * 2;
-    static constexpr size_t p_w1_hi = p_wp_lo + size_t(C) * KC * 2, p_w1_lo = p_w1_hi + size_t(HID) * KC * 2;
-    static constexpr size_t p_w2_hi = p_w1_lo + size_t(HID) * KC * 2, p_w2_lo = p_w2_hi + size_t(C) * LDW2 * 2;
-    static constexpr size_t p_vec = (p_w2_lo + size_t(C) * LDW2 * 2 + 15) / 16 * 16;           // fp32 vectors
-    static constexpr int v_ln1g = 0, v_ln1b = KC, v_ln2g = 2 * KC, v_ln2b = 3 * KC, v_bqkv = 4 * KC, v_bp = v_bqkv + 3 * C, v_b2 = v_bp + C,
-                         v_b1 = v_b2 + C, v_end = v_b1 + KH;
-    static constexpr size_t wsec = (p_vec + size_t(v_end) * 4 + 15) / 16 * 16;
-    static constexpr size_t p_bias4 = wsec;                                                   // [4 variants][64 keys][64 queries] fp32, global only
-    static constexpr size_t p_total = p_bias4 + size_t(4) * T * T * 4;
-
-    // ---- LDS carve (bytes) ----
-    static constexpr size_t img = size_t(2) * T * LDC * 2;                // one token-major bf16 image [2 streams][64][LDC]
-    static constexpr size_t l_ahi = 0;                                    // A image (xn / O / xn2 / hidden chunk), hi and lo parts
-    static constexpr size_t l_alo = l_ahi + img;
-    // QALO: in the 32-tokens-per-wave layout a wave's queries are its own tokens and its own A rows are dead between the Q/K/V
-    // projections (x fragments sit in registers) and the O stores; head h's O-lo store overwrites only head h's Q channels, which
-    // were consumed by then (the other heads' k-steps mask them out).  So Q is written into the A-lo rows: one image less.
-    static constexpr bool QALO = C == 48 && SWF_C48_TWO_WG && SWF_C48_TT2;
-    static constexpr size_t l_q = QALO ? l_alo : l_alo + img;              // Q (pre-scaled) and K, bf16, all channels of a token in one row
-    static constexpr size_t l_k = l_alo + img + (QALO ? 0 : img);
-    static constexpr size_t l_vt = l_k + img;                             // fp16 [2][C] x VRS: V^T, keys in MFMA k order
-    static constexpr int ONES_ROW = 2 * C;                                // extra V^T row of 1.0: its product with P^T is the softmax denominator
-    static constexpr size_t l_mask = l_vt + size_t(2 * C + 1) * VRS * 2;  // [8 heads][NKS][2 lane halves] x 16 B: channel masks of a head
-    static constexpr size_t l_w = (l_mask + size_t(HEADS) * NKS * 2 * 16 + 15) / 16 * 16;   // the two streams' weight sections
-    // L2-sourced weights: the fp32 vectors (LN gamma / beta, biases) of both streams are still staged into LDS — every one
-    // of their loads would otherwise expose an L2 round trip (one wave per SIMD at C = 96 hides nothing)
-    static constexpr size_t vsec = (size_t(v_end) * 4 + 15) / 16 * 16;
-    static constexpr size_t l_total = l_w + (WLDS ? 2 * wsec : 2 * vsec);
-    static_assert(l_total <= 160 * 1024, "window tile (+ weights) exceed the 160 KiB LDS of a CU");
-};
-
-// L2-sourced weight fragments: stop hipcc from hoisting every iteration's global loads to the loop top (it would
-// spill); a compiler-only fence, no instruction.
-#define SWF_LOAD_FENCE(G_) do { if constexpr (!G_::WLDS && !ROOMY) asm volatile("" ::: "memory"); } while (0)
-
-struct WinArgs {
-    const float* in[2];
-    float* out[2];
-    const char* packed[2];
-    const char* warm[2];     // packed images of the NEXT block of the stage (or nullptr): touched at the end of this launch
-    int B, H, W, shift, cross;
-    int warm_bytes;          // bytes of one packed image to touch
-    int ws;                  // window side: 8, or 7 (the reference's default) on the same 8x8 token grid — the 15 padding tokens read
-                             // a neighbouring token (any finite row serves: as keys they carry probability 0 in the packed bias
-                             // matrices, as queries they are never stored)
-};
 
 // ------------------------------------------------------------------------------------------
 // device helpers
@@ -191,589 +77,6 @@ __device__ __forceinline__ int vt_pos(int tok) {
     return (tok & 48) | (h << 3) | e;
 }
 
-// split-bf16 operand fragment of one 16-row tile (rows = lanes&15, 8 consecutive k per lane group), all k-steps
-template <int KSTEPS>
-struct Frag {
-    bf16x8 hi[KSTEPS], lo[KSTEPS];
-};
-
-template <int KSTEPS, int LD>
-__device__ __forceinline__ void load_frag(Frag<KSTEPS>& f, const bf16* hi, const bf16* lo, int row, int g, int k0 = 0) {
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        f.hi[ks] = *reinterpret_cast<const bf16x8*>(hi + row * LD + k0 + ks * 32 + 8 * g);
-        f.lo[ks] = *reinterpret_cast<const bf16x8*>(lo + row * LD + k0 + ks * 32 + 8 * g);
-    }
-}
-
-// chunk swizzle of a K-major weight row (Geo::WSWZ): with q = (n >> 2) & 3 the map 0,1,2,3 -> 0,3,2,1 (and any rotation of
-// it by 2: fragments start at rows = 0 or 8 mod 16) gives the lanes {r16 in 0-3,12-15 | g} and {r16 in 4-11 | g^1} of one
-// ds_read_b128 group four different chunk positions inside every 64-byte bank quarter
-__host__ __device__ __forceinline__ constexpr int wswz(int n) { return (-(n >> 2)) & 3; }
-
-template <int KSTEPS, int LD, bool SWZ>
-__device__ __forceinline__ void load_frag_w(Frag<KSTEPS>& f, const bf16* hi, const bf16* lo, int row, int g) {
-    if constexpr (SWZ) {
-        static_assert(KSTEPS == 1, "the chunk swizzle covers one 32-deep k-step");
-        load_frag<KSTEPS, LD>(f, hi, lo, row, g ^ wswz(row));
-    } else {
-        load_frag<KSTEPS, LD>(f, hi, lo, row, g);
-    }
-}
-
-// D[16 rows of a][16 rows of b] += a . b^T with split-bf16 operands: three MFMAs per k-step, small cross
-// terms first so they are not absorbed by the large hi.hi partial sums.  Result register j of a lane is
-// (a-row 4*(lane>>4)+j, b-row lane&15).
-template <int KSTEPS>
-__device__ __forceinline__ f32x4 mma_bf16x3(const Frag<KSTEPS>& a, const Frag<KSTEPS>& b, f32x4 acc) {
-#pragma unroll
-    for (int ks = 0; ks < KSTEPS; ++ks) {
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.lo[ks], b.hi[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi[ks], b.lo[ks], acc, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a.hi[ks], b.hi[ks], acc, 0, 0, 0);
-    }
-    return acc;
-}
-
-// LayerNorm of the wave's 16 residual rows, straight from registers, into its rows of the split-bf16 A image.
-// Register layout = MFMA output layout of the transposed tiles: lane (r16 = token, g) holds res[nt] = channels
-// nt*16 + 4g .. +3.  A token's channels sit in the 4 lanes with equal r16: two xor-shuffles finish the sums.
-// Columns C..KC-1 (K padding) are written as exact zeros (gamma / beta are stored zero-padded).
-template <typename G>
-__device__ __forceinline__ void layernorm_regs(const float4 (&res)[G::NTK], bf16* ahi_rows, bf16* alo_rows, const float* vec,
-                                               int goff, int boff, int r16, int g) {
-    constexpr int C = G::C;
-    float sum = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < G::NTK; ++nt) sum += (res[nt].x + res[nt].y) + (res[nt].z + res[nt].w);   // padding registers hold zeros
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    const float mean = sum * (1.0f / C);
-    float var = 0.f;
-#pragma unroll
-    for (int nt = 0; nt < G::NTK; ++nt) {
-        if (nt * 16 + 4 * g < C) {
-            const float a = res[nt].x - mean, b = res[nt].y - mean, c = res[nt].z - mean, d = res[nt].w - mean;
-            var += (a * a + b * b) + (c * c + d * d);
-        }
-    }
-    var += __shfl_xor(var, 16);
-    var += __shfl_xor(var, 32);
-    const float rstd = __builtin_amdgcn_rsqf(var * (1.0f / C) + 1e-5f);   // v_rsq_f32 (1 ulp) instead of an IEEE divide + sqrt
-#pragma unroll
-    for (int nt = 0; nt < G::NTK; ++nt) {
-        const int c0 = nt * 16 + 4 * g;
-        const float4 gm = *reinterpret_cast<const float4*>(vec + goff + c0);
-        const float4 bt = *reinterpret_cast<const float4*>(vec + boff + c0);
-        const float n[4] = {(res[nt].x - mean) * rstd * gm.x + bt.x, (res[nt].y - mean) * rstd * gm.y + bt.y,
-                            (res[nt].z - mean) * rstd * gm.z + bt.z, (res[nt].w - mean) * rstd * gm.w + bt.w};
-        bf16x4 h, l;
-        split4_bf16(n, h, l);
-        *reinterpret_cast<bf16x4*>(ahi_rows + r16 * G::LDC + c0) = h;
-        *reinterpret_cast<bf16x4*>(alo_rows + r16 * G::LDC + c0) = l;
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// the block kernel: persistent, one workgroup per CU walks the windows.
-// Wave w owns token rows [16*(w&3), +16) of stream w>>2 for every per-token phase (LN, projections, MLP):
-// those phases need no workgroup barrier.  Only attention mixes tokens: one barrier before, one after.
-// ------------------------------------------------------------------------------------------
-// TT = 16-token tiles per wave.  TT = 1: 512 threads, wave w owns tokens [16(w&3), +16) of stream w>>2.  TT = 2 (C = 48):
-// 256 threads, wave w owns tokens [32(w&1), +32) of stream w>>1: every weight fragment a wave pulls from L2 feeds two MFMAs
-// (half the L1->register traffic per token, the measured bound of the L2-sourced variants) and two workgroups share a CU.
-template <int C_, int HID_, int TT>
-__global__ __launch_bounds__(512 / TT, TT == 2 ? (Geo<C_, HID_>::SMALL_L2 ? 3 : (Geo<C_, HID_>::QALO ? 2 : 1)) : 2) void window_block_kernel(WinArgs args) {
-    using G = Geo<C_, HID_>;
-    constexpr int C = G::C, D = G::D, T = G::T, LDC = G::LDC, KS = G::KC / 32;
-    constexpr int NTHR = 512 / TT;              // threads per workgroup
-    // Letting hipcc hoist the L2-sourced weight fragment loads where registers allow (C = 96, TT = 2: one wave per SIMD, 512
-    // registers; no fences, unroll 3) measured 127 us against 98 us fenced: the fences stay on for every L2-sourced variant.
-    constexpr bool ROOMY = false;
-    static_assert(TT == 1 || TT == 2, "one or two 16-token tiles per wave");
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    bf16* ahi = reinterpret_cast<bf16*>(smem + G::l_ahi);
-    bf16* alo = reinterpret_cast<bf16*>(smem + G::l_alo);
-    f16* qimg = reinterpret_cast<f16*>(smem + G::l_q);   // Q (pre-scaled) and K images: f16 (Q.K^T operands; same MFMA rate as bf16, 8x the mantissa)
-    f16* kimg = reinterpret_cast<f16*>(smem + G::l_k);
-    f16* vt = reinterpret_cast<f16*>(smem + G::l_vt);
-    uint4* maskt = reinterpret_cast<uint4*>(smem + G::l_mask);
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#ifdef SWF_WIN_PROBE
-    if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0) swf_win_probe[10] = wall_clock64();
-#endif
-    const int H = args.H, W = args.W;
-    const int wside = args.ws;
-    const int nwx = W / wside, nwy = H / wside;
-    const int nwin = args.B * nwx * nwy;
-    const int sh = args.shift ? wside / 2 : 0, sw = sh;
-
-    auto wsec = [&](int s) -> const char* { return G::WLDS ? smem + G::l_w + s * G::wsec : args.packed[s]; };
-    auto wmat = [&](int s, size_t off) { return reinterpret_cast<const bf16*>(wsec(s) + off); };
-    auto wvec = [&](int s) {
-        return G::WLDS ? reinterpret_cast<const float*>(smem + G::l_w + s * G::wsec + G::p_vec) : reinterpret_cast<const float*>(smem + G::l_w + s * G::vsec);
-    };
-
-    // ---- once per workgroup: weights -> LDS, zero the images (the K padding of Q / K rows is never written
-    //      again and must read as exact zeros), build the per-head channel masks ----
-    {
-        if constexpr (G::WLDS) {
-            constexpr int W16 = G::wsec / 16;
-            for (int i = tid; i < 2 * W16; i += NTHR) {
-                const int s = i / W16, e = i % W16;
-                reinterpret_cast<uint4*>(smem + G::l_w + s * G::wsec)[e] = reinterpret_cast<const uint4*>(args.packed[s])[e];
-            }
-        }
-        if constexpr (!G::WLDS) {
-            for (int i = tid; i < 2 * G::v_end; i += NTHR) {
-                const int s = i / G::v_end, e = i % G::v_end;
-                reinterpret_cast<float*>(smem + G::l_w + s * G::vsec)[e] = reinterpret_cast<const float*>(args.packed[s] + G::p_vec)[e];
-            }
-        }
-        constexpr int Z16 = (G::l_vt - G::l_ahi) / 16;
-        uint4* z = reinterpret_cast<uint4*>(smem + G::l_ahi);
-        for (int i = tid; i < Z16; i += NTHR) z[i] = make_uint4(0, 0, 0, 0);
-        for (int i = tid; i < G::VRS; i += NTHR) vt[G::ONES_ROW * G::VRS + i] = (f16)1.0f;
-        for (int i = tid; i < G::HEADS * G::NKS * 2; i += NTHR) {
-            const int hf = i & 1, ks = (i >> 1) % G::NKS, head = i / (2 * G::NKS);
-            unsigned m[4];
-#pragma unroll
-            for (int dwd = 0; dwd < 4; ++dwd) {
-                const int ch = ks * 16 + hf * 8 + dwd * 2;
-                m[dwd] = ((ch >= head * D && ch < head * D + D) ? 0xFFFFu : 0u) | ((ch + 1 >= head * D && ch + 1 < head * D + D) ? 0xFFFF0000u : 0u);
-            }
-            maskt[i] = make_uint4(m[0], m[1], m[2], m[3]);
-        }
-    }
-
-    // the wave's own 16 token rows live in registers for the whole block: lane (r16, g) holds, per 16-channel
-    // tile nt, the 4 channels nt*16 + 4g .. +3 of token wm*16 + r16 (the MFMA output layout of the transposed tiles)
-    const int ws = wave / (4 / TT), wm0 = (wave % (4 / TT)) * TT;   // stream and first 16-token tile this wave owns
-    const int r16 = lane & 15, g = lane >> 4;
-    constexpr int NTK = G::NTK;
-    float4 res[TT][NTK], pre[TT][NTK];
-    auto token_base = [&](int win, int tt) -> int64_t {
-        const int b = win / (nwx * nwy), wrem = win % (nwx * nwy);
-        const int wy = wrem / nwx, wx = wrem % nwx;
-        const int tok = (wm0 + tt) * 16 + r16;
-        const int oy = (wy * wside + (tok >> 3) + sh) % H, ox = (wx * wside + (tok & 7) + sw) % W;   // roll(-s): read at (y+s)%H
-        return (((int64_t)b * H + oy) * W + ox) * C;
-    };
-#define SWF_PREFETCH(WIN)                                                                                   \
-    do {                                                                                                    \
-        _Pragma("unroll") for (int tt = 0; tt < TT; ++tt) {                                                 \
-            const float* src_ = args.in[ws] + token_base(WIN, tt);                                          \
-            _Pragma("unroll") for (int nt = 0; nt < NTK; ++nt)                                              \
-                pre[tt][nt] = (nt * 16 + 4 * g < C) ? *reinterpret_cast<const float4*>(src_ + nt * 16 + 4 * g) \
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);                      \
-        }                                                                                                   \
-    } while (0)
-    bf16* my_ahi = ahi + (ws * T + wm0 * 16) * LDC;   // tile tt of this wave: + tt * 16 * LDC
-    bf16* my_alo = alo + (ws * T + wm0 * 16) * LDC;
-
-    int win = blockIdx.x;
-    // three workgroups per CU (SMALL_L2): the other waves cover a window's load latency and the 16 prefetch registers are
-    // the difference between spilling and not, so the rows are loaded at the top of their own window
-    constexpr bool PREFETCH_AHEAD = !G::SMALL_L2 && !G::QALO;
-    if (PREFETCH_AHEAD && win < nwin) SWF_PREFETCH(win);
-    int cur_variant = -1;
-    f32x16 bfr[2];   // relative-position bias (+mask) of this wave's (stream, query block), S^T layout, exp2 units
-    __syncthreads();
-
-    for (; win < nwin; win += gridDim.x) {
-        const int wrem = win % (nwx * nwy);
-        const int wy = wrem / nwx, wx = wrem % nwx;
-        // ---- own rows: prefetched registers become the residual; start fetching the next window ----
-        if constexpr (!PREFETCH_AHEAD) SWF_PREFETCH(win);
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-            for (int nt = 0; nt < NTK; ++nt) res[tt][nt] = pre[tt][nt];
-        if (PREFETCH_AHEAD && win + (int)gridDim.x < nwin) SWF_PREFETCH(win + gridDim.x);
-
-        SWF_WPROBE(0);
-#ifdef SWF_WIN_PROBE
-        if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0) swf_win_probe[11] = wall_clock64();
-#endif
-        // ---- LN1 -> A image (own rows) ----
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-            layernorm_regs<G>(res[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, wvec(ws), G::v_ln1g, G::v_ln1b, r16, g);
-
-        SWF_WPROBE(1);
-        // ---- Q, K, V projections of the own rows.  Q for the own stream; K and V for the stream whose attention
-        //      reads these tokens as keys: itself, or the other one in a cross block (a002:67-82) ----
-        {
-            Frag<KS> x[TT];
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) load_frag<KS, LDC>(x[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, r16, g);
-            const int kvs = args.cross ? 1 - ws : ws;
-            constexpr int NT_UNROLL = G::WLDS ? G::NTC : (ROOMY ? 2 : 1);   // see HC_UNROLL
-#pragma unroll NT_UNROLL
-            for (int nt = 0; nt < G::NTC; ++nt) {
-                const int ch4 = nt * 16 + 4 * g;           // this lane's 4 output channels (transposed tiles)
-                const int wrow = nt * 16 + r16 < C ? nt * 16 + r16 : 0;
-                Frag<KS> wq, wk, wv;
-                load_frag_w<KS, G::KC, G::WSWZ>(wq, wmat(ws, G::p_wqkv_hi), wmat(ws, G::p_wqkv_lo), wrow, g);
-                load_frag_w<KS, G::KC, G::WSWZ>(wk, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), C + wrow, g);
-                load_frag_w<KS, G::KC, G::WSWZ>(wv, wmat(kvs, G::p_wqkv_hi), wmat(kvs, G::p_wqkv_lo), 2 * C + wrow, g);
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) {
-                    const int trow = (wm0 + tt) * 16;          // first token row of this tile inside the window
-                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 aq = mma_bf16x3<KS>(wq, x[tt], z4);   // [channel 4g+j][token r16]
-                    const f32x4 ak = mma_bf16x3<KS>(wk, x[tt], z4);
-                    const f32x4 av = mma_bf16x3<KS>(x[tt], wv, z4);   // [token 4g+j][channel r16]
-                    if (ch4 < G::KC) {   // columns C..KC-1 are the K padding: rewritten as zeros (the MLP's hidden chunks reuse these rows)
-                        f16x4 q4 = {0, 0, 0, 0}, k4 = {0, 0, 0, 0};
-                        if (ch4 < C) {
-                            const float4 bq = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bqkv + ch4);
-                            const float4 bk = *reinterpret_cast<const float4*>(wvec(kvs) + G::v_bqkv + C + ch4);
-                            q4 = f16x4{(f16)(aq[0] + bq.x), (f16)(aq[1] + bq.y), (f16)(aq[2] + bq.z), (f16)(aq[3] + bq.w)};
-                            k4 = f16x4{(f16)(ak[0] + bk.x), (f16)(ak[1] + bk.y), (f16)(ak[2] + bk.z), (f16)(ak[3] + bk.w)};
-                        }
-                        *reinterpret_cast<f16x4*>(qimg + (ws * T + trow + r16) * LDC + ch4) = q4;
-                        *reinterpret_cast<f16x4*>(kimg + (kvs * T + trow + r16) * LDC + ch4) = k4;
-                    }
-                    const int chv = nt * 16 + r16;
-                    if (chv < C) {
-                        const float bv = wvec(kvs)[G::v_bqkv + 2 * C + chv];
-                        f16x4 v4 = {(f16)(av[0] + bv), (f16)(av[1] + bv), (f16)(av[2] + bv), (f16)(av[3] + bv)};
-                        *reinterpret_cast<f16x4*>(vt + (kvs * C + chv) * G::VRS + vt_pos(trow + 4 * g)) = v4;
-                    }
-                }
-                SWF_LOAD_FENCE(G);
-            }
-        }
-        SWF_WPROBE(2);
-        __syncthreads();   // all Q / K / V^T rows of the window are in place
-
-        SWF_WPROBE(3);
-        // ---- attention.  wave -> (stream, 32-query block, 4 heads) ----
-        {
-            // TT = 1: wave -> (stream, 32-query block, 4 heads);  TT = 2: wave -> (stream, 32-query block), all 8 heads
-            const int s = ws, qb = TT == 1 ? (wave >> 1) & 1 : wave & 1, h0 = TT == 1 ? (wave & 1) * 4 : 0;
-            const int r = lane & 31, hf = lane >> 5;
-            const int variant = args.shift ? ((wy == nwy - 1) * 2 + (wx == nwx - 1)) : 0;
-            // SMALL_L2 (3 waves per SIMD, 168 registers): the 32 bias registers are reloaded for every window (L2 hits) so they
-            // are dead outside the attention phase
-            if (G::SMALL_L2 || variant != cur_variant) {   // wave-uniform; only edge windows of shifted blocks differ
-                cur_variant = variant;
-                const float* bias4 = reinterpret_cast<const float*>(args.packed[s] + G::p_bias4) + variant * T * T;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) bfr[kt][i] = bias4[(32 * kt + (i & 3) + 8 * (i >> 2) + 4 * hf) * T + 32 * qb + r];
-            }
-            const f16* qrow = qimg + (s * T + 32 * qb + r) * LDC + 8 * hf;
-            const f16* krow0 = kimg + (s * T + r) * LDC + 8 * hf;
-            const f16* krow1 = krow0 + 32 * LDC;
-            constexpr int HEAD_UNROLL = (G::NTK <= 2 && TT == 1) ? SWF_HEAD_UNROLL_C24 : 1;   // heads in flight while the residual registers are few
-#pragma unroll HEAD_UNROLL
-            for (int hh = 0; hh < 4 * TT; ++hh) {
-                const int head = h0 + hh;
-                // S^T = K . Qmasked^T: K rows carry all channels, the Q fragment is ANDed with the head's channel mask,
-                // so only the 16-deep k-steps that the head's channels touch are issued (1 or 2 for D <= 16).  The
-                // bias (+mask) registers are the C operand of the first step: no accumulator copy.
-                const int ks_lo = (head * D) >> 4, ks_hi = (head * D + D - 1) >> 4;
-                f32x16 acc0, acc1;
-                {
-                    const uint4 mk = maskt[(head * G::NKS + ks_lo) * 2 + hf];
-                    uint4 qv = *reinterpret_cast<const uint4*>(qrow + ks_lo * 16);
-                    qv.x &= mk.x; qv.y &= mk.y; qv.z &= mk.z; qv.w &= mk.w;
-                    const f16x8 qf = __builtin_bit_cast(f16x8, qv);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow0 + ks_lo * 16), qf, bfr[0], 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow1 + ks_lo * 16), qf, bfr[1], 0, 0, 0);
-                }
-                for (int ks = ks_lo + 1; ks <= ks_hi; ++ks) {
-                    const uint4 mk = maskt[(head * G::NKS + ks) * 2 + hf];
-                    uint4 qv = *reinterpret_cast<const uint4*>(qrow + ks * 16);
-                    qv.x &= mk.x; qv.y &= mk.y; qv.z &= mk.z; qv.w &= mk.w;
-                    const f16x8 qf = __builtin_bit_cast(f16x8, qv);
-                    acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow0 + ks * 16), qf, acc0, 0, 0, 0);
-                    acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow1 + ks * 16), qf, acc1, 0, 0, 0);
-                }
-                // row max over the lane's 32 keys with v_max3 (hipcc would emit canonicalising v_max pairs), then
-                // across the two lane halves
-                float mx = max3f(acc0[0], acc0[1], acc1[0]);
-                mx = max3f(mx, acc1[1], acc0[2]);
-#pragma unroll
-                for (int i = 3; i < 16; i += 2) mx = max3f(mx, acc0[i], acc0[i + 1 < 16 ? i + 1 : i]);
-#pragma unroll
-                for (int i = 2; i < 16; i += 2) mx = max3f(mx, acc1[i], acc1[i + 1]);
-                mx = fmaxf(mx, __shfl_xor(mx, 32));
-                const f32x2 m2 = {mx, mx};
-#pragma unroll
-                for (int i = 0; i < 16; i += 2) {
-                    f32x2 a = {acc0[i], acc0[i + 1]}, b = {acc1[i], acc1[i + 1]};
-                    a -= m2; b -= m2;
-                    acc0[i] = __builtin_amdgcn_exp2f(a[0]); acc0[i + 1] = __builtin_amdgcn_exp2f(a[1]);
-                    acc1[i] = __builtin_amdgcn_exp2f(b[0]); acc1[i + 1] = __builtin_amdgcn_exp2f(b[1]);
-                }
-                // O^T = V^T . P^T; row D of the V^T operand is all ones, so row D of the result is the softmax
-                // denominator, summed by the MFMA from the same fp16-rounded P that feeds the numerator
-                f32x16 o[G::MT];
-#pragma unroll
-                for (int mt = 0; mt < G::MT; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) o[mt][i] = 0.f;
-#pragma unroll
-                for (int kt = 0; kt < 2; ++kt)
-#pragma unroll
-                    for (int s2 = 0; s2 < 2; ++s2) {
-                        f16x8 pf;
-#pragma unroll
-                        for (int e = 0; e < 8; ++e) pf[e] = (f16)(kt == 0 ? acc0[8 * s2 + e] : acc1[8 * s2 + e]);
-#pragma unroll
-                        for (int mt = 0; mt < G::MT; ++mt) {
-                            // rows beyond the head width read the ones row: row D of the product is then the denominator
-                            // (rows D+1.. are never read back)
-                            const int c = mt * 32 + r;
-                            const int vrow = c < D ? s * C + head * D + c : G::ONES_ROW;
-                            const f16x8 va = *reinterpret_cast<const f16x8*>(vt + vrow * G::VRS + kt * 32 + s2 * 16 + 8 * hf);
-                            o[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(va, pf, o[mt], 0, 0, 0);
-                        }
-                    }
-                // the denominator sits in tile D/32, register (D&3) + 4*((D&31)>>3), lane half (D>>2)&1
-                constexpr int LM = D / 32, LI = (D & 3) + 4 * ((D & 31) >> 3), LH = (D >> 2) & 1;
-                float l = o[LM][LI];
-                const float l_other = __shfl_xor(l, 32);
-                l = (hf == LH) ? l : l_other;
-                const float inv = __builtin_amdgcn_rcpf(l);   // v_rcp_f32: 1 ulp, the tier's budget is 1e-3
-                const int tok = 32 * qb + r;
-#pragma unroll
-                for (int mt = 0; mt < G::MT; ++mt)
-#pragma unroll
-                    for (int i = 0; i < 16; ++i) {
-                        const int c = mt * 32 + (i & 3) + 8 * (i >> 2) + 4 * hf;
-                        if (c < D) {
-                            const float ov = o[mt][i] * inv;
-                            const bf16 hi = (bf16)ov;
-                            ahi[(s * T + tok) * LDC + head * D + c] = hi;   // xn is dead: the A image now carries O
-                            alo[(s * T + tok) * LDC + head * D + c] = (bf16)(ov - (float)hi);
-                        }
-                    }
-            }
-        }
-        SWF_WPROBE(4);
-        __syncthreads();   // O rows complete
-
-        SWF_WPROBE(5);
-        // ---- output projection + residual (own rows; transposed tiles: a lane holds 4 channels of one token) ----
-        {
-            Frag<KS> x[TT];
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) load_frag<KS, LDC>(x[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, r16, g);
-#pragma unroll
-            for (int nt = 0; nt < G::NTC; ++nt) {   // fully unrolled: res[] must be indexed statically
-                const int ch4 = nt * 16 + 4 * g;
-                Frag<KS> wp;
-                load_frag_w<KS, G::KC, G::WSWZ>(wp, wmat(ws, G::p_wp_hi), wmat(ws, G::p_wp_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g);
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) {
-                    const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                    const f32x4 acc = mma_bf16x3<KS>(wp, x[tt], z4);
-                    if (ch4 < C) {
-                        const float4 bp = *reinterpret_cast<const float4*>(wvec(ws) + G::v_bp + ch4);
-                        res[tt][nt].x += acc[0] + bp.x; res[tt][nt].y += acc[1] + bp.y; res[tt][nt].z += acc[2] + bp.z; res[tt][nt].w += acc[3] + bp.w;
-                    }
-                }
-                SWF_LOAD_FENCE(G);
-            }
-        }
-
-        // Rotating-register MLP weights (C = 96, TT = 2: one wave per SIMD, nothing else hides an L2 round trip, and 512
-        // registers to spend): the fc1 fragments (+ bias) of chunk hc+1 are requested as soon as chunk hc's fc1 MFMAs have
-        // consumed theirs, the fc2 fragments of chunk hc+1 as soon as chunk hc's fc2 MFMAs have; chunk 0's go out here, under
-        // LN2.  Scheduling fences pin the issue points (hipcc otherwise sinks the loads next to their uses).
-        constexpr bool ROT = !G::WLDS && TT == 2 && SWF_MLP_ROTATE && G::HID % 32 == 0 && C > 24 && !G::QALO;   // C = 24 runs 3 waves per SIMD: no registers to spare
-        Frag<ROT ? KS : 1> w1a, w1b;
-        Frag<1> w2r[ROT ? G::NTC : 1];
-        float4 b1a, b1b;
-        auto req_fc1 = [&](int hc) {
-            if constexpr (ROT) {
-                b1a = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hc * 32 + 4 * g);
-                b1b = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hc * 32 + 16 + 4 * g);
-                load_frag_w<KS, G::KC, G::WSWZ>(w1a, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hc * 32 + r16, g);
-                load_frag_w<KS, G::KC, G::WSWZ>(w1b, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hc * 32 + 16 + r16, g);
-            }
-        };
-        auto req_fc2 = [&](int hc) {
-            if constexpr (ROT) {
-#pragma unroll
-                for (int nt = 0; nt < G::NTC; ++nt)
-                    load_frag<1, G::LDW2>(w2r[nt], wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), nt * 16 + r16 < C ? nt * 16 + r16 : 0, g, hc * 32);
-            }
-        };
-        if constexpr (ROT) {
-            req_fc1(0);
-            req_fc2(0);
-            __builtin_amdgcn_sched_barrier(0);
-        }
-
-        SWF_WPROBE(6);
-        // ---- LN2 -> A image (own rows) ----
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt)
-            layernorm_regs<G>(res[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, wvec(ws), G::v_ln2g, G::v_ln2b, r16, g);
-
-        SWF_WPROBE(7);
-        // ---- MLP, own rows, walking the hidden dimension in chunks of 32: fc1 + ELU for the chunk -> split-bf16
-        //      image over the wave's own A rows (xn2 already sits in registers) -> one k-step of fc2.  The hidden
-        //      activations never exist as a whole. ----
-        {
-            Frag<KS> x[TT];
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt) load_frag<KS, LDC>(x[tt], my_ahi + tt * 16 * LDC, my_alo + tt * 16 * LDC, r16, g);
-            f32x4 out[TT][G::NTC];
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-                for (int nt = 0; nt < G::NTC; ++nt) out[tt][nt] = f32x4{0.f, 0.f, 0.f, 0.f};
-            // two chunk buffers so consecutive chunks do not serialise on one LDS region: the wave's A rows, and
-            // the Q / K rows it wrote for this window (dead since the post-attention barrier; the projections of
-            // the next window rewrite them, K padding included)
-            // (QALO: no Q image — both halves of the second buffer share the K rows, hi in columns 0-31, lo in 32-63)
-            bf16* const krows = reinterpret_cast<bf16*>(kimg) + ((args.cross ? 1 - ws : ws) * T + wm0 * 16) * LDC;   // dead K rows, reused as a bf16 image
-            bf16* hb_hi[2] = {my_ahi, G::QALO ? krows : reinterpret_cast<bf16*>(qimg) + (ws * T + wm0 * 16) * LDC};
-            bf16* hb_lo[2] = {my_alo, G::QALO ? krows + 32 : krows};
-            if constexpr (!ROT) {
-            constexpr int HC_UNROLL = G::WLDS ? G::KH / 32 : (ROOMY ? 3 : 2);   // L2-sourced weights: full unrolling hoists every fragment load and spills
-#pragma unroll HC_UNROLL
-            for (int hc = 0; hc < G::KH / 32; ++hc) {
-                bf16* hhi = hb_hi[hc & 1];
-                bf16* hlo = hb_lo[hc & 1];
-#pragma unroll
-                for (int t2 = 0; t2 < 2; ++t2) {
-                    const int hid0 = hc * 32 + t2 * 16;
-                    if (hid0 < G::HID) {   // compile-time: tiles wholly in the K padding are just zeros
-                        Frag<KS> w1;
-                        load_frag_w<KS, G::KC, G::WSWZ>(w1, wmat(ws, G::p_w1_hi), wmat(ws, G::p_w1_lo), hid0 + r16 < G::HID ? hid0 + r16 : 0, g);
-                        const float4 b1 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b1 + hid0 + 4 * g);
-#pragma unroll
-                        for (int tt = 0; tt < TT; ++tt) {
-                            const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                            const f32x4 acc = mma_bf16x3<KS>(w1, x[tt], z4);   // [hidden 4g+j][token r16]
-                            float v[4] = {acc[0] + b1.x, acc[1] + b1.y, acc[2] + b1.z, acc[3] + b1.w};
-#pragma unroll
-                            for (int j = 0; j < 4; ++j) v[j] = (hid0 + 4 * g + j < G::HID) ? elu_fast(v[j]) : 0.f;
-                            bf16x4 h4, l4;
-                            split4_bf16(v, h4, l4);
-                            *reinterpret_cast<bf16x4*>(hhi + (tt * 16 + r16) * LDC + t2 * 16 + 4 * g) = h4;
-                            *reinterpret_cast<bf16x4*>(hlo + (tt * 16 + r16) * LDC + t2 * 16 + 4 * g) = l4;
-                        }
-                    } else {
-                        const bf16x4 z = {0, 0, 0, 0};
-#pragma unroll
-                        for (int tt = 0; tt < TT; ++tt) {
-                            *reinterpret_cast<bf16x4*>(hhi + (tt * 16 + r16) * LDC + t2 * 16 + 4 * g) = z;
-                            *reinterpret_cast<bf16x4*>(hlo + (tt * 16 + r16) * LDC + t2 * 16 + 4 * g) = z;
-                        }
-                    }
-                    SWF_LOAD_FENCE(G);
-                }
-                Frag<1> hfrag[TT];
-#pragma unroll
-                for (int tt = 0; tt < TT; ++tt) load_frag<1, LDC>(hfrag[tt], hhi + tt * 16 * LDC, hlo + tt * 16 * LDC, r16, g);
-#pragma unroll
-                for (int nt = 0; nt < G::NTC; ++nt) {
-                    Frag<1> w2;
-                    {
-                        const int w2row = nt * 16 + r16 < C ? nt * 16 + r16 : 0;
-                        load_frag<1, G::LDW2>(w2, wmat(ws, G::p_w2_hi), wmat(ws, G::p_w2_lo), w2row, G::WSWZ ? g ^ wswz(w2row) : g, hc * 32);
-                    }
-#pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) out[tt][nt] = mma_bf16x3<1>(w2, hfrag[tt], out[tt][nt]);
-                    if ((nt & 1) == 1) SWF_LOAD_FENCE(G);
-                }
-            }
-            } else {
-                constexpr int NCH = G::KH / 32;
-#pragma unroll 2
-                for (int hc = 0; hc < NCH; ++hc) {
-                    bf16* hhi = hb_hi[hc & 1];
-                    bf16* hlo = hb_lo[hc & 1];
-                    const int hcn = hc + 1 < NCH ? hc + 1 : hc;   // past the last chunk: dead re-loads instead of a branch
-                    f32x4 acc_a[TT], acc_b[TT];
-#pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) {
-                        const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-                        acc_a[tt] = mma_bf16x3<KS>(w1a, x[tt], z4);   // [hidden 4g+j][token r16]
-                        acc_b[tt] = mma_bf16x3<KS>(w1b, x[tt], z4);
-                    }
-                    const float4 ba = b1a, bb = b1b;
-                    __builtin_amdgcn_sched_barrier(0);
-                    req_fc1(hcn);
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) {
-                        float va[4] = {elu_fast(acc_a[tt][0] + ba.x), elu_fast(acc_a[tt][1] + ba.y), elu_fast(acc_a[tt][2] + ba.z), elu_fast(acc_a[tt][3] + ba.w)};
-                        float vb[4] = {elu_fast(acc_b[tt][0] + bb.x), elu_fast(acc_b[tt][1] + bb.y), elu_fast(acc_b[tt][2] + bb.z), elu_fast(acc_b[tt][3] + bb.w)};
-                        bf16x4 h4, l4;
-                        split4_bf16(va, h4, l4);
-                        *reinterpret_cast<bf16x4*>(hhi + (tt * 16 + r16) * LDC + 4 * g) = h4;
-                        *reinterpret_cast<bf16x4*>(hlo + (tt * 16 + r16) * LDC + 4 * g) = l4;
-                        split4_bf16(vb, h4, l4);
-                        *reinterpret_cast<bf16x4*>(hhi + (tt * 16 + r16) * LDC + 16 + 4 * g) = h4;
-                        *reinterpret_cast<bf16x4*>(hlo + (tt * 16 + r16) * LDC + 16 + 4 * g) = l4;
-                    }
-                    Frag<1> hfrag[TT];
-#pragma unroll
-                    for (int tt = 0; tt < TT; ++tt) load_frag<1, LDC>(hfrag[tt], hhi + tt * 16 * LDC, hlo + tt * 16 * LDC, r16, g);
-#pragma unroll
-                    for (int nt = 0; nt < G::NTC; ++nt)
-#pragma unroll
-                        for (int tt = 0; tt < TT; ++tt) out[tt][nt] = mma_bf16x3<1>(w2r[nt], hfrag[tt], out[tt][nt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    req_fc2(hcn);
-                    __builtin_amdgcn_sched_barrier(0);
-                }
-            }
-#pragma unroll
-            for (int tt = 0; tt < TT; ++tt)
-#pragma unroll
-                for (int nt = 0; nt < G::NTC; ++nt) {
-                    const int ch4 = nt * 16 + 4 * g;
-                    if (ch4 < C) {
-                        const float4 b2 = *reinterpret_cast<const float4*>(wvec(ws) + G::v_b2 + ch4);
-                        res[tt][nt].x += out[tt][nt][0] + b2.x; res[tt][nt].y += out[tt][nt][1] + b2.y;
-                        res[tt][nt].z += out[tt][nt][2] + b2.z; res[tt][nt].w += out[tt][nt][3] + b2.w;
-                    }
-                }
-        }
-
-        SWF_WPROBE(8);
-        // ---- store the own rows (un-shift = same index map as the load) ----
-#pragma unroll
-        for (int tt = 0; tt < TT; ++tt) {
-            float* dst = args.out[ws] + token_base(win, tt);
-            const int tok = (wm0 + tt) * 16 + r16;
-            if ((tok >> 3) >= wside || (tok & 7) >= wside) continue;   // padding token of a 7x7 window
-#pragma unroll
-            for (int nt = 0; nt < NTK; ++nt)
-                if (nt * 16 + 4 * g < C) *reinterpret_cast<float4*>(dst + nt * 16 + 4 * g) = res[tt][nt];
-        }
-        SWF_WPROBE(9);
-#ifdef SWF_WIN_PROBE
-        if (blockIdx.x == SWF_WIN_PROBE && threadIdx.x == 0) swf_win_probe[12] = wall_clock64();
-#endif
-    }
-#undef SWF_PREFETCH
-    // ---- L2 warm-up for the next block of the stage.  Its weights were last used a whole forward ago: cold, every fragment
-    //      load of the next launch would go to HBM / MALL (measured at C = 96: 58 us with warm weights, 78 us in the model).
-    //      The L2s are per XCD and blocks are dealt to XCDs round-robin (speed only), so the workgroups of one XCD together
-    //      touch the whole image: workgroup b covers slice b / 8 of gridDim.x / 8 slices.  Issued last: nothing waits on it. ----
-    if (args.warm[0]) {
-        const int nsl = max(1, (int)gridDim.x / 8), sl = ((int)blockIdx.x / 8) % nsl;
-        const int lines = (args.warm_bytes + 127) / 128;                       // 128-byte lines of one image
-        const int per = (lines + nsl - 1) / nsl, l0 = sl * per, l1 = min(lines, l0 + per);
-        unsigned acc = 0;
-        for (int s2 = 0; s2 < 2; ++s2)
-            for (int l = l0 + tid; l < l1; l += NTHR) acc ^= *reinterpret_cast<const unsigned*>(args.warm[s2] + (size_t)l * 128);
-        if (acc == 0x9e3779b9u && args.B < 0) args.out[0][0] = 0.f;   // never true: keeps the loads alive
-    }
-}
 
 // ------------------------------------------------------------------------------------------
 // Stand-alone MFMA attention core for 8x8 windows (levels whose linears run as separate GEMMs):
@@ -1315,170 +618,30 @@ int launch_attn_core_mfma(const float* const* Q, const float* const* K, const fl
     }
     return fail(SWF_ERR_UNSUPPORTED, "attn_core_mfma: head_dim %d", head_dim);
 }
-
-// ------------------------------------------------------------------------------------------
-// weight packing: fp32 nn.Parameter tensors -> the kernel layout above
-// ------------------------------------------------------------------------------------------
-struct PackArgs {
-    swf_block_stream_params p[2];
-    char* dst[2];
-    int head_dim;
-    int ws;   // window side (7 or 8)
-};
-
-template <int C_, int HID_>
-__global__ __launch_bounds__(256) void pack_block_kernel(PackArgs a) {
-    using G = Geo<C_, HID_>;
-    constexpr int C = G::C, HID = G::HID, T = G::T;
-    const int s = blockIdx.y;
-    const swf_block_stream_params& p = a.p[s];
-    char* dst = a.dst[s];
-    const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
-    const float qscale = kLog2e / sqrtf((float)G::D);   // d^-0.5 (a001:32-34) and the exp -> exp2 change of base
-
-    float* vec = reinterpret_cast<float*>(dst + G::p_vec);
-    const swf_linear* qkv[3] = {&p.attn.q, &p.attn.k, &p.attn.v};
-    for (int i = gtid; i < G::v_end; i += gsz) {
-        float v = 0.f;
-        if (i < G::v_bqkv) {   // LayerNorm gamma / beta, each padded to KC with zeros
-            const int which = i / G::KC, c = i % G::KC;
-            const float* src = which == 0 ? p.ln1.gamma : which == 1 ? p.ln1.beta : which == 2 ? p.ln2.gamma : p.ln2.beta;
-            v = c < C ? src[c] : 0.f;
-        } else if (i < G::v_bp) {
-            const int which = (i - G::v_bqkv) / C, n = (i - G::v_bqkv) % C;
-            v = qkv[which]->bias ? qkv[which]->bias[n] : 0.f;
-            if (which == 0) v *= qscale;
-        } else if (i < G::v_b2) v = p.attn.proj.bias ? p.attn.proj.bias[i - G::v_bp] : 0.f;
-        else if (i < G::v_b1) v = p.fc2.bias ? p.fc2.bias[i - G::v_b2] : 0.f;
-        else v = (i - G::v_b1 < HID && p.fc1.bias) ? p.fc1.bias[i - G::v_b1] : 0.f;
-        vec[i] = v;
-    }
-    auto put = [&](size_t off_hi, size_t off_lo, int idx, float v) {
-        bf16 hi = (bf16)v;
-        bf16 lo = (bf16)(v - (float)hi);
-        reinterpret_cast<bf16*>(dst + off_hi)[idx] = hi;
-        reinterpret_cast<bf16*>(dst + off_lo)[idx] = lo;
-    };
-    // position of element (row, k) of a K-major matrix: chunk-swizzled when the rows are read from LDS (Geo::WSWZ)
-    auto kpos = [](int row, int k) { return row * G::KC + (G::WSWZ ? (((k >> 3) ^ wswz(row)) << 3) + (k & 7) : k); };
-    for (int i = gtid; i < 3 * C * G::KC; i += gsz) {
-        const int which = i / (C * G::KC), n = (i / G::KC) % C, k = i % G::KC;
-        float v = k < C ? qkv[which]->weight[n * C + k] : 0.f;
-        if (which == 0) v *= qscale;
-        put(G::p_wqkv_hi, G::p_wqkv_lo, kpos(which * C + n, k), v);   // rows of the stacked [3C][KC] matrix
-    }
-    for (int i = gtid; i < C * G::KC; i += gsz) {
-        const int n = i / G::KC, k = i % G::KC;
-        put(G::p_wp_hi, G::p_wp_lo, kpos(n, k), k < C ? p.attn.proj.weight[n * C + k] : 0.f);
-    }
-    for (int i = gtid; i < HID * G::KC; i += gsz) {
-        const int n = i / G::KC, k = i % G::KC;
-        put(G::p_w1_hi, G::p_w1_lo, kpos(n, k), k < C ? p.fc1.weight[n * C + k] : 0.f);
-    }
-    for (int i = gtid; i < C * G::LDW2; i += gsz) {
-        const int n = i / G::LDW2, k = i % G::LDW2;
-        // LDS-resident: chunks swizzled inside every 32-wide k-step (rows are a multiple of 64 bytes); else padded rows
-        const int pos = G::WSWZ ? n * G::LDW2 + (k & ~31) + ((((k >> 3) & 3) ^ wswz(n)) << 3) + (k & 7) : i;
-        put(G::p_w2_hi, G::p_w2_lo, pos, k < HID ? p.fc2.weight[n * HID + k] : 0.f);
-    }
-    // relative-position bias (a001:113-144) with the shift mask (a001:217-315) folded in, four variants:
-    // bit1 = window in the last window row, bit0 = window in the last window column.  Only those windows
-    // contain more than one region label; inside them the label bands split at wh - wh/2 (ww - ww/2).
-    // (7x7 windows on the 8x8 grid: a padding token as key is masked in every variant, as query it gets a zero row)
-    const int WH = a.ws, WW = a.ws, TW = 2 * WW - 1;
-    for (int i = gtid; i < 4 * T * T; i += gsz) {
-        const int variant = i / (T * T), key = (i / T) % T, q = i % T;
-        const int ky = key >> 3, kx = key & 7, qy = q >> 3, qx = q & 7;
-        const bool pad_k = ky >= WH || kx >= WW, pad_q = qy >= WH || qx >= WW;
-        float v = (pad_k || pad_q) ? 0.f : p.attn.bias_table[(ky - qy + WH - 1) * TW + (kx - qx + WW - 1)];
-        const bool my = (variant & 2) && ((ky >= WH - WH / 2) != (qy >= WH - WH / 2));
-        const bool mx = (variant & 1) && ((kx >= WW - WW / 2) != (qx >= WW - WW / 2));
-        if (my || mx || pad_k) v = -1e10f;
-        reinterpret_cast<float*>(dst + G::p_bias4)[i] = v * kLog2e;
-    }
-}
-
 // ------------------------------------------------------------------------------------------
 // host dispatch
 // ------------------------------------------------------------------------------------------
-#define SWF_WINDOW_SHAPES(X) X(24, 96) X(24, 4) X(48, 192) X(48, 96) X(96, 384) X(96, 192)
+// Levels 0 / 1 / 2 (C = 24 / 48 / 96) run on the register-resident kernels of kernels_win24.hip / kernels_win48.hip /
+// kernels_win96.hip.  Their token rows travel through 32-bit buffer descriptors, so ONE launch covers at most 2^31 - 1 bytes
+// of a stream's map; images are independent (LayerNorm per token, attention per window), so a larger batch is launched in
+// batch slices (launch_window_block) and only a single image beyond that size is left to the unfused tier.
+static bool use_win24(const swf_block_desc& d) { return win24_supported(d); }
+static bool use_win48(const swf_block_desc& d) { return win48_supported(d); }
+static bool use_win96(const swf_block_desc& d) { return win96_supported(d); }
 
-// one persistent workgroup per CU (its LDS footprint admits exactly one)
-static int num_cus() {
-    static int n = [] {
-        int dev = 0, v = 0;
-        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || v <= 0) v = 256;
-        return v;
-    }();
-    return n;
-}
-
-template <int C, int HID>
-static int launch_t(const WinArgs& a, int nwin, hipStream_t stream) {
-    using G = Geo<C, HID>;
-    // C = 48 / 96: two 16-token tiles per wave, 256-thread workgroups, one per CU (94 / 145 KB of LDS)
-    constexpr int TT = (G::SMALL_L2 || (C == 48 && SWF_C48_TT2) || (C == 96 && SWF_C96_TT2)) ? 2 : 1;
-    constexpr int PER_CU = G::SMALL_L2 ? 3 : (G::QALO ? 2 : 1);   // resident workgroups per CU
-    static std::once_flag once;
-    static hipError_t attr_err = hipSuccess;
-    std::call_once(once, [] {
-        attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&window_block_kernel<C, HID, TT>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)G::l_total);
-    });
-    if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window_block): %s", hipGetErrorString(attr_err));
-    hipLaunchKernelGGL((window_block_kernel<C, HID, TT>), dim3(std::min(nwin, PER_CU * num_cus())), dim3(512 / TT), G::l_total, stream, a);
-    return check_launch("window_block");
-}
-
-template <int C, int HID>
-static int pack_t(const PackArgs& a, hipStream_t stream) {
-    hipLaunchKernelGGL((pack_block_kernel<C, HID>), dim3(32, 2), dim3(256), 0, stream, a);
-    return check_launch("pack_window_block");
-}
-
-// Level 0 (C = 24) runs on the register-resident kernel of kernels_win24.hip; SWF_WIN24=0 (read once per process) keeps the
-// LDS-tile kernel of this file for A/B runs.  The two use different packed images, so the switch covers pack and launch alike.
-static bool use_win24(const swf_block_desc& d) {
-    static const bool on = [] { const char* e = std::getenv("SWF_WIN24"); return !(e && e[0] == '0'); }();
-    return on && win24_supported(d);
-}
-
-// Level 1 (C = 48) likewise on kernels_win48.hip; SWF_WIN48=0 keeps the LDS-tile kernel of this file.
-static bool use_win48(const swf_block_desc& d) {
-    static const bool on = [] { const char* e = std::getenv("SWF_WIN48"); return !(e && e[0] == '0'); }();
-    return on && win48_supported(d);
-}
-
-// Level 2 (C = 96) likewise on kernels_win96.hip; SWF_WIN96=0 keeps the LDS-image kernel of this file
-static bool use_win96(const swf_block_desc& d) {
-    static const bool on = [] { const char* e = std::getenv("SWF_WIN96"); return !(e && e[0] == '0'); }();
-    return on && win96_supported(d);
-}
-
-static bool dims_match(const swf_block_desc& d, int C, int HID) {
-    return d.attn.channels == C && d.hidden == HID && d.attn.heads == 8 && d.attn.head_dim * 8 == C && d.attn.win_h == d.attn.win_w &&
-           (d.attn.win_h == 8 || d.attn.win_h == 7);
-}
+static int64_t image_bytes(const swf_block_desc& d, int H, int W) { return (int64_t)H * W * d.attn.channels * 4; }
+constexpr int64_t kMaxLaunchBytes = (int64_t(1) << 31) - 1;
 
 bool window_block_supported(const swf_block_desc& d, int B, int H, int W) {
     if (B <= 0 || H <= 0 || W <= 0) return false;
-    if (use_win24(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 24 * 4 < (int64_t(1) << 31);
-    if (use_win48(d)) return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 48 * 4 < (int64_t(1) << 31);
-    if (use_win96(d) && H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && (int64_t)B * H * W * 96 * 4 < (int64_t(1) << 31)) return true;
-    if (H % d.attn.win_h || W % d.attn.win_w) return false;
-#define X(C, HID) if (dims_match(d, C, HID)) return true;
-    SWF_WINDOW_SHAPES(X)
-#undef X
-    return false;
+    if (!(use_win24(d) || use_win48(d) || use_win96(d))) return false;
+    return H % d.attn.win_h == 0 && W % d.attn.win_w == 0 && image_bytes(d, H, W) <= kMaxLaunchBytes;
 }
 
 size_t window_block_packed_bytes(const swf_block_desc& d) {
     if (use_win24(d)) return win24_packed_bytes(d);
     if (use_win48(d)) return win48_packed_bytes(d);
     if (use_win96(d)) return win96_packed_bytes(d);
-#define X(C, HID) if (dims_match(d, C, HID)) return align_up(Geo<C, HID>::p_total, 256);
-    SWF_WINDOW_SHAPES(X)
-#undef X
     return 0;
 }
 
@@ -1499,14 +662,6 @@ int pack_window_block(const swf_block_desc& d, const swf_block_stream_params& px
     if (use_win24(d)) return pack_win24(d, px, py, packed_x, packed_y, stream);
     if (use_win48(d)) return pack_win48(d, px, py, packed_x, packed_y, stream);
     if (use_win96(d)) return pack_win96(d, px, py, packed_x, packed_y, stream);
-    PackArgs a;
-    a.p[0] = px; a.p[1] = py;
-    a.dst[0] = static_cast<char*>(packed_x); a.dst[1] = static_cast<char*>(packed_y);
-    a.head_dim = d.attn.head_dim;
-    a.ws = d.attn.win_h;
-#define X(C, HID) if (dims_match(d, C, HID)) return pack_t<C, HID>(a, stream);
-    SWF_WINDOW_SHAPES(X)
-#undef X
     return fail(SWF_ERR_UNSUPPORTED, "pack_window_block: C=%d hidden=%d not covered", d.attn.channels, d.hidden);
 }
 
@@ -1529,23 +684,25 @@ int launch_l2_warm(const void* p, size_t bytes, hipStream_t stream) {
 int launch_window_block(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in,
                         const float* y_in, float* x_out, float* y_out, int B, int H, int W, hipStream_t stream,
                         const void* next_packed_x, const void* next_packed_y, size_t next_bytes) {
-    if (use_win24(d)) return launch_win24(d, packed_x, packed_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_packed_x, next_packed_y, next_bytes);
-    if (use_win48(d)) return launch_win48(d, packed_x, packed_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_packed_x, next_packed_y, next_bytes);
-    if (use_win96(d)) return launch_win96(d, packed_x, packed_y, x_in, y_in, x_out, y_out, B, H, W, stream, next_packed_x, next_packed_y, next_bytes);
-    WinArgs a;
-    a.warm[0] = static_cast<const char*>(next_packed_x); a.warm[1] = static_cast<const char*>(next_packed_y);
-    if (!a.warm[1]) a.warm[0] = nullptr;
-    a.warm_bytes = (int)(next_bytes ? next_bytes : window_block_packed_bytes(d));
-    a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
-    a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
-    a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross;
-    a.ws = d.attn.win_h;
-    if (H % a.ws || W % a.ws) return fail(SWF_ERR_UNSUPPORTED, "window_block: %d x %d map, window %d", H, W, a.ws);
-    const int nwin = B * (H / a.ws) * (W / a.ws);
-#define X(C, HID) if (dims_match(d, C, HID)) return launch_t<C, HID>(a, nwin, stream);
-    SWF_WINDOW_SHAPES(X)
-#undef X
-    return fail(SWF_ERR_UNSUPPORTED, "window_block: C=%d hidden=%d not covered", d.attn.channels, d.hidden);
+    if (!window_block_supported(d, B, H, W))
+        return fail(SWF_ERR_UNSUPPORTED, "window_block: C=%d hidden=%d, %d x %d map, window %d not covered", d.attn.channels, d.hidden, H, W, d.attn.win_h);
+    // batch slices of at most 2^31 - 1 bytes per stream map (32-bit buffer offsets inside the kernels); the slice size depends on
+    // the map size only, and a slice runs exactly the kernel the whole batch would: rows are bit-identical either way
+    const int64_t img = image_bytes(d, H, W);
+    const int per = (int)std::min<int64_t>(B, kMaxLaunchBytes / img);
+    for (int b0 = 0; b0 < B; b0 += per) {
+        const int nb = std::min(per, B - b0);
+        const size_t off = (size_t)b0 * (size_t)(img / 4);
+        const bool last = b0 + nb >= B;   // only the last slice touches the next block's packed weights (L2 warm-up)
+        const void* nx = last ? next_packed_x : nullptr;
+        const void* ny = last ? next_packed_y : nullptr;
+        int st;
+        if (use_win24(d)) st = launch_win24(d, packed_x, packed_y, x_in + off, y_in + off, x_out + off, y_out + off, nb, H, W, stream, nx, ny, next_bytes);
+        else if (use_win48(d)) st = launch_win48(d, packed_x, packed_y, x_in + off, y_in + off, x_out + off, y_out + off, nb, H, W, stream, nx, ny, next_bytes);
+        else st = launch_win96(d, packed_x, packed_y, x_in + off, y_in + off, x_out + off, y_out + off, nb, H, W, stream, nx, ny, next_bytes);
+        if (st != SWF_OK) return st;
+    }
+    return SWF_OK;
 }
 
 }  // namespace swf

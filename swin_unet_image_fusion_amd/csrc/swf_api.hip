@@ -276,7 +276,7 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
         h_hi[s] = planes(N * hid); h_lo[s] = planes(N * hid);
     }
     int64_t skn = std::max((int64_t)gemm_sp_splitk_for(HD, SP_EPI_F32), (int64_t)gemm_sp_splitk_for(hid, SP_EPI_F32));
-    static const bool no_fused_mlp = std::getenv("SWF_NO_FUSED_MLP") != nullptr;   // A/B switch
+    static const bool no_fused_mlp = debug_env("SWF_NO_FUSED_MLP") != nullptr;   // A/B switch
     const bool fused_mlp = !no_fused_mlp && mlp_fused_supported(C, hid) && N <= INT32_MAX / 2;
     if (fused_mlp) skn = std::max(skn, (int64_t)mlp_fused_splits(C, hid));
     const int64_t sk_floats = skn > 1 ? skn * nstream * N * C : 0;
@@ -284,8 +284,8 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
     // Output projection folded into its neighbours (C = 192 levels): qkv_attn writes the two head-group partial sums of
     // O . Wp^T, the fused MLP kernel's prologue adds x + bias + both and normalises — no projection GEMM launch, O never
     // reaches HBM.  (Carved last so the LN1 planes keep their offsets from block to block.)
-    static const bool no_qkvattn = std::getenv("SWF_NO_QKVATTN") != nullptr;     // A/B switches
-    static const bool no_projfuse = std::getenv("SWF_NO_PROJFUSE") != nullptr;
+    static const bool no_qkvattn = debug_env("SWF_NO_QKVATTN") != nullptr;     // A/B switches
+    static const bool no_projfuse = debug_env("SWF_NO_PROJFUSE") != nullptr;
     const bool fused_attn_shape = !no_qkvattn && qkvattn_supported(*desc) && N <= INT32_MAX / 256;
     // Measured: +0.5 % on the step at B=16 256x256 (16x16 maps at this level), -1.7 % at 512x512 — the extra rows the MLP prologue
     // pulls per workgroup only pay while its grid under-fills the chip.  The rule looks at the map size, never at the batch, so
@@ -483,7 +483,7 @@ static int basic_block_impl(const swf_block_desc* desc, const swf_block_stream_p
     };
     const uintptr_t tbits = reinterpret_cast<uintptr_t>(x_in) | reinterpret_cast<uintptr_t>(y_in) | reinterpret_cast<uintptr_t>(x_out) |
                             reinterpret_cast<uintptr_t>(y_out);
-    static const bool no_deep = std::getenv("SWF_NO_DEEP") != nullptr;   // A/B switch for tools/profile_block.py
+    static const bool no_deep = debug_env("SWF_NO_DEEP") != nullptr;   // A/B switch for tools/profile_block.py
     if (deep_block_supported(*desc) && !no_deep && tbits % 16 == 0 && aligned16(px) && aligned16(py)) {
         Carver ws(workspace, workspace_bytes);
         return deep_block_impl(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, stream, prepacked_x, prepacked_y, next_p, ln1_ready);
@@ -528,8 +528,8 @@ static int patch_merge_impl(const swf_patch_params* const* p, int nstream, const
     SWF_TRY(merge_shapes(H, W, mh, mw, wh, ww, &Hm, &Wm, &Ho, &Wo));
     const int64_t N = (int64_t)B * Ho * Wo;
     const int K = mh * mw * Cin;
-    static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switches
-    static const bool no_prr = std::getenv("SWF_NO_PATCH_RR") != nullptr;
+    static const bool no_fused = debug_env("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switches
+    static const bool no_prr = debug_env("SWF_NO_PATCH_RR") != nullptr;
     const bool use_prr = fast && !no_fused && !no_prr && prr && nstream == 2 && patch_rr_supported(0, Cin, Cout, mh, mw) &&
                          (int64_t)B * H * W * Cin < (int64_t(1) << 31);
     const bool use_dp = fast && !no_fused && !use_prr && prr && deep_patch_supported(0, Cin, Cout, mh, mw) && (int64_t)B * H * W * Cin < (int64_t(1) << 31);
@@ -618,8 +618,8 @@ static int patch_unmerge_impl(const swf_patch_params* const* p, int nstream, con
     const int64_t N = (int64_t)B * Hm * Wm;
     const int Kz = mh * mw * Cout;
     const bool need_crop = (Hm != Hp) || (Wm != Wp);
-    static const bool no_fused = std::getenv("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switches
-    static const bool no_prr = std::getenv("SWF_NO_PATCH_RR") != nullptr;
+    static const bool no_fused = debug_env("SWF_NO_FUSED_PATCH") != nullptr;   // A/B switches
+    static const bool no_prr = debug_env("SWF_NO_PATCH_RR") != nullptr;
     const bool use_prr = fast && !no_fused && !no_prr && prr && nstream == 2 && patch_rr_supported(1, Cin, Cout, mh, mw) &&
                          (int64_t)B * Hp * Wp * Cin < (int64_t(1) << 31);
     const bool use_dp = fast && !no_fused && !use_prr && prr && deep_patch_supported(1, Cin, Cout, mh, mw) && (int64_t)B * Hp * Wp * Cin < (int64_t(1) << 31);
@@ -980,10 +980,11 @@ size_t swf_window_attention_workspace_bytes(const swf_attn_desc* desc, int32_t B
     return attention_generic_ws(*desc, 1, B, H, W);
 }
 
-int swf_window_attention_fwd(const swf_attn_desc* desc, const swf_attn_params* p, const float* q, const float* k,
-                             const float* v, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
-                             void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+static int window_attention_impl(const swf_attn_desc* desc, int precision, const swf_attn_params* p, const float* q, const float* k,
+                                 const float* v, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
+                                 void* workspace, size_t workspace_bytes, swf_stream_t stream) {
     SWF_TRY(check_attn_desc(desc, B, H, W));
+    if (precision != SWF_PREC_FP32 && precision != SWF_PREC_FAST) return fail(SWF_ERR_BAD_SHAPE, "window_attention: unknown precision %d", precision);
     if (!p || !q || !k || !v || !out) return fail(SWF_ERR_NULL, "window_attention: NULL tensor or params");
     if (!p->q.weight || !p->k.weight || !p->v.weight || !p->proj.weight || !p->bias_table)
         return fail(SWF_ERR_NULL, "window_attention: NULL weight");
@@ -994,7 +995,20 @@ int swf_window_attention_fwd(const swf_attn_desc* desc, const swf_attn_params* p
     const float* vs[2] = {v, nullptr};
     const float* rs[2] = {residual, nullptr};
     float* os[2] = {out, nullptr};
-    return attention_generic(*desc, 1, prm, qs, ks, vs, residual ? rs : nullptr, os, B, H, W, ws, as_stream(stream));
+    return attention_generic(*desc, 1, prm, qs, ks, vs, residual ? rs : nullptr, os, B, H, W, ws, as_stream(stream),
+                             precision == SWF_PREC_FAST ? 1 : 0);
+}
+
+int swf_window_attention_fwd(const swf_attn_desc* desc, const swf_attn_params* p, const float* q, const float* k,
+                             const float* v, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
+                             void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    return window_attention_impl(desc, SWF_PREC_FP32, p, q, k, v, residual, out, B, H, W, workspace, workspace_bytes, stream);
+}
+
+int swf_window_attention_fwd_prec(const swf_attn_desc* desc, int32_t precision, const swf_attn_params* p, const float* q, const float* k,
+                                  const float* v, const float* residual, float* out, int32_t B, int32_t H, int32_t W,
+                                  void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    return window_attention_impl(desc, precision, p, q, k, v, residual, out, B, H, W, workspace, workspace_bytes, stream);
 }
 
 size_t swf_basic_block_workspace_bytes(const swf_block_desc* desc, int32_t B, int32_t H, int32_t W) {
@@ -1116,6 +1130,27 @@ int swf_linear_fwd(const swf_linear* lin, const float* in, const float* residual
     GemmBatch gb{};
     gb.p[0] = GemmProb{in, lin->weight, lin->bias, residual, out};
     return launch_gemm_f32(gb, 1, (int)tokens, n_out, n_in, n_in, n_out, act, as_stream(stream));
+}
+
+size_t swf_linear_workspace_bytes(int32_t precision, int64_t tokens, int32_t n_in, int32_t n_out) {
+    if (precision != SWF_PREC_FAST || tokens <= 0 || n_in <= 0 || n_out <= 0) return 0;
+    return carve_bytes({splitk_need(n_in, tokens * n_out)});
+}
+
+int swf_linear_fwd_prec(const swf_linear* lin, int32_t precision, const float* in, const float* residual, float* out, int64_t tokens,
+                        int32_t n_in, int32_t n_out, int32_t act, void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    if (precision == SWF_PREC_FP32) return swf_linear_fwd(lin, in, residual, out, tokens, n_in, n_out, act, stream);
+    if (precision != SWF_PREC_FAST) return fail(SWF_ERR_BAD_SHAPE, "linear: unknown precision %d", precision);
+    if (!lin || !lin->weight || !in || !out) return fail(SWF_ERR_NULL, "linear: NULL argument");
+    if (tokens <= 0 || tokens > INT32_MAX || n_in <= 0 || n_out <= 0) return fail(SWF_ERR_BAD_SHAPE, "linear: bad sizes");
+    if (act != 0 && act != 1) return fail(SWF_ERR_UNSUPPORTED, "linear: activation %d", act);
+    Carver ws(workspace, workspace_bytes);
+    GemmBatch gb{};
+    gb.scratch_floats = splitk_need(n_in, tokens * n_out);
+    gb.scratch = ws.floats(gb.scratch_floats);
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "linear: workspace too small (need %zu B)", ws.used);
+    gb.p[0] = GemmProb{in, lin->weight, lin->bias, residual, out};
+    return launch_gemm_bf16x3(gb, 1, (int)tokens, n_out, n_in, n_in, n_out, act, as_stream(stream));
 }
 
 int swf_layernorm_fwd(const swf_norm* ln, const float* in, float* out, int64_t tokens, int32_t C, int32_t elu, swf_stream_t stream) {
@@ -1263,7 +1298,8 @@ int swf_model_pack_weights(const swf_model_desc* desc, const float* arena, void*
 
 static int model_forward_impl(const swf_model_desc* desc, const float* arena, const char* packed, const float* ir, const float* vis, float* out,
                               int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream_,
-                              int32_t* equal_flags = nullptr) {
+                              int32_t* equal_flags = nullptr, hipEvent_t* marks = nullptr) {
+    // marks (swf_model_forward_profiled): 4 * levels + 2 events, recorded on the stream at the start and after every segment
     SWF_TRY(check_model_desc(desc));
     const PackedPlan plan = packed_plan(desc);
     if (!arena || !ir || !vis || !out) return fail(SWF_ERR_NULL, "model_forward: NULL tensor");
@@ -1286,6 +1322,12 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
 
     auto patch_params = [&](const PatchOff& o) { return swf_patch_params{{arena + o.w, arena + o.b}, {arena + o.g, arena + o.bt}}; };
 
+    int nmark = 0;
+    auto mark = [&]() -> int {
+        if (marks && hipEventRecord(marks[nmark++], stream) != hipSuccess) return fail(SWF_ERR_HIP, "model_forward: hipEventRecord failed");
+        return SWF_OK;
+    };
+    SWF_TRY(mark());
     // encoder (a013:215-220)
     const float* cur[2] = {ir, vis};
     bool ln1_carry = false;   // deep levels: the LN1 planes of the next block to run are in place (deep_ln1_planes)
@@ -1304,6 +1346,7 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
         SWF_TRY(patch_merge_impl(pmp, 2, cur, act[s], B, ls[s].Hin, ls[s].Win, desc->in_dims[s], desc->out_dims[s], desc->merge_h,
                                  desc->merge_w, desc->win_h, desc->win_w, scratch, scratch_bytes, stream, desc->precision == SWF_PREC_FAST,
                                  (packed && plan.penc_b[s]) ? prr_enc : nullptr, deep_stage ? first_blk : nullptr, deep_stage ? &ln1_carry : nullptr));
+        SWF_TRY(mark());
         // the first block of the next fused-kernel stage is warmed by this stage's last block
         const char* after = nullptr;
         size_t after_pb = 0;
@@ -1317,6 +1360,7 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
                                  (packed && plan.enc_on[s]) ? packed + plan.enc[s] : nullptr, after, after_pb,
                                  equal_flags ? equal_flags + 2 * s : nullptr, chain ? dec_first : nullptr, deep_stage ? &ln1_carry : nullptr));
         if (!chain) ln1_carry = false;
+        SWF_TRY(mark());
         cur[0] = act[s][0]; cur[1] = act[s][1];
     }
     // decoder (a013:221-227): the skip add of stage j+1 is folded into stage j's unmerge epilogue,
@@ -1336,6 +1380,7 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
         SWF_TRY(block_pair4_impl(&bd, px, py, act[lvl][0], act[lvl][1], act[lvl][0], act[lvl][1], B, ls[lvl].Ho, ls[lvl].Wo, scratch, scratch_bytes, stream,
                                  (packed && plan.dec_on[j]) ? packed + plan.dec[j] : nullptr, after, after_pb,
                                  equal_flags ? equal_flags + 2 * (n + j) : nullptr, nullptr, &ln1_in));
+        SWF_TRY(mark());
         // a deep-level stage cannot warm its successor from inside a block kernel: its patch layer does it (or one small launch)
         const bool warm_next = after && window_block_packed_bytes(bd) == 0;
         bool warmed = false;
@@ -1362,11 +1407,13 @@ static int model_forward_impl(const swf_model_desc* desc, const float* arena, co
                                    warm_next ? after : nullptr, warm_next ? after_pb : 0, &warmed, next_deep ? next_first : nullptr,
                                    next_deep ? &ln1_carry : nullptr));
         if (warm_next && !warmed) SWF_TRY(launch_l2_warm(after, 2 * after_pb, stream));
+        SWF_TRY(mark());
     }
     swf_head_params hp{arena + L->h_c1w, arena + L->h_c1b, arena + L->h_g, arena + L->h_b, arena + L->h_m, arena + L->h_v,
                        arena + L->h_c2w, arena + L->h_c2b};
     float* tmp = static_cast<float*>(scratch);
-    return launch_head(full[0], full[1], tmp, out, hp, B, H, W, desc->head_ksize, stream);
+    SWF_TRY(launch_head(full[0], full[1], tmp, out, hp, B, H, W, desc->head_ksize, stream));
+    return mark();
 }
 
 int swf_model_forward(const swf_model_desc* desc, const float* arena, const float* ir, const float* vis, float* out,
@@ -1388,6 +1435,26 @@ int swf_model_forward_checked(const swf_model_desc* desc, const float* arena, co
     if (e != hipSuccess) return fail(SWF_ERR_HIP, "model_forward_checked: memset: %s", hipGetErrorString(e));
     return model_forward_impl(desc, arena, static_cast<const char*>(packed), ir, vis, out, B, H, W, workspace, workspace_bytes, stream,
                               cross_equal_flags);
+}
+
+int swf_model_forward_profiled(const swf_model_desc* desc, const float* arena, const void* packed, const float* ir, const float* vis,
+                               float* out, int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, float* seg_ms,
+                               int32_t seg_count, swf_stream_t stream) {
+    if (!seg_ms) return fail(SWF_ERR_NULL, "model_forward_profiled: NULL seg_ms");
+    if (check_model_desc(desc) != SWF_OK) return SWF_ERR_BAD_SHAPE;
+    const int nseg = 4 * desc->levels + 1;
+    if (seg_count < nseg) return fail(SWF_ERR_BAD_SHAPE, "model_forward_profiled: seg_ms holds %d values, need %d", seg_count, nseg);
+    hipEvent_t ev[4 * SWF_MAX_LEVELS + 2];
+    int made = 0, st = SWF_OK;
+    for (; made < nseg + 1; ++made)
+        if (hipEventCreate(&ev[made]) != hipSuccess) { st = fail(SWF_ERR_HIP, "model_forward_profiled: hipEventCreate failed"); break; }
+    if (st == SWF_OK)
+        st = model_forward_impl(desc, arena, static_cast<const char*>(packed), ir, vis, out, B, H, W, workspace, workspace_bytes, stream, nullptr, ev);
+    if (st == SWF_OK && hipStreamSynchronize(as_stream(stream)) != hipSuccess) st = fail(SWF_ERR_HIP, "model_forward_profiled: synchronize failed");
+    for (int i = 0; st == SWF_OK && i < nseg; ++i)
+        if (hipEventElapsedTime(&seg_ms[i], ev[i], ev[i + 1]) != hipSuccess) st = fail(SWF_ERR_HIP, "model_forward_profiled: hipEventElapsedTime failed");
+    for (int i = 0; i < made; ++i) (void)hipEventDestroy(ev[i]);
+    return st;
 }
 
 int swf_tensors_equal(const float* a, const float* b, int64_t count, int32_t* flag, swf_stream_t stream) {

@@ -4,6 +4,7 @@
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 
 #include "../../include/swinfuse.h"
@@ -21,6 +22,15 @@ inline int check_launch(const char* what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return fail(SWF_ERR_HIP, "%s: %s", what, hipGetErrorString(e));
     return SWF_OK;
+}
+
+// A/B switches of the dispatch (every one selects between HIP kernels of this library; there is no CPU path).  They are
+// read ONLY when SWF_DEBUG_SWITCHES=1 is set as well, so that a stray variable in a production environment — or on one rank of a
+// sharded job, where it would break the bit-identity of batch shards — cannot change the kernel path.  tests/test_gpu_switches.py
+// runs the main fallbacks in child processes with the opt-in set.
+inline const char* debug_env(const char* name) {
+    static const bool on = [] { const char* e = std::getenv("SWF_DEBUG_SWITCHES"); return e && e[0] == '1'; }();
+    return on ? std::getenv(name) : nullptr;
 }
 
 inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }

@@ -77,6 +77,13 @@ def _workspace(nbytes: int, device) -> Tuple[Optional[int], int]:
     return buf.data_ptr(), buf.numel()
 
 
+def _workspace_tensor(device, stream_handle: int) -> Optional[Tensor]:
+    """The scratch buffer currently registered for (device, raw stream handle), or None.  Whoever bakes its address into a
+    captured hipGraph (shard.ShardedFusion) keeps this tensor alive: _workspace() replaces the registered buffer when a later
+    call on the same stream handle needs more bytes, and torch recycles stream handles from a small pool."""
+    return _WS.get((torch.device(device).index, stream_handle))
+
+
 def _check_forward_only(module: nn.Module, *tensors: Optional[Tensor]) -> None:
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
         raise RuntimeError("libswinfuse provides the forward pass only; call it under torch.no_grad() "
@@ -167,6 +174,7 @@ class WindowAttention(_FwdAlias, nn.Module):
         self.attention_drop_ratio, self.linear_after_att_drop_ratio = attention_drop_ratio, linear_after_att_drop_ratio
         self.qk_scale = dims_per_head ** -0.5
         self.feature_shape_hw: tuple = tuple()
+        self.precision = "fast"   # arithmetic tier of this module's own forward: "fast" (MFMA, <= 1e-3) or "fp32" (exact)
         hd = num_heads * dims_per_head
         self.q_for_heads = nn.Linear(in_out_dims, hd, bias=use_qkv_bias)
         self.k_for_heads = nn.Linear(in_out_dims, hd, bias=use_qkv_bias)
@@ -204,8 +212,8 @@ class WindowAttention(_FwdAlias, nn.Module):
         lib = L.lib()
         ws, wsn = _workspace(lib.swf_window_attention_workspace_bytes(C.byref(desc), b, h, w), q.device)
         prm = self._params()
-        L.check(lib.swf_window_attention_fwd(C.byref(desc), C.byref(prm), _ptr(qn), _ptr(kn), _ptr(vn), None,
-                                             _ptr(out), b, h, w, ws, wsn, _stream(q.device)))
+        L.check(lib.swf_window_attention_fwd_prec(C.byref(desc), _precision_code(self.precision), C.byref(prm), _ptr(qn), _ptr(kn),
+                                                  _ptr(vn), None, _ptr(out), b, h, w, ws, wsn, _stream(q.device)))
         return _to_nchw(out)
 
 
@@ -246,6 +254,7 @@ class AutoPathMLP(_FwdAlias, nn.Module):
         super().__init__()
         self.in_out_dims, self.hidden_dims, self.activation_func = in_out_dims, hidden_dims, activation_func
         self.use_dual_path, self.drop_ratio = use_dual_path, drop_ratio
+        self.precision = "fast"
         for s in ("x", "y") if use_dual_path else ("x",):
             c1 = nn.Conv2d(in_out_dims, hidden_dims, kernel_size=1)
             c2 = nn.Conv2d(hidden_dims, in_out_dims, kernel_size=1)
@@ -267,8 +276,11 @@ class AutoPathMLP(_FwdAlias, nn.Module):
         out = torch.empty((b, h, w, c), dtype=torch.float32, device=t.device)
         l1, l2 = _lin(getattr(self, f"mlp_{s}_1")), _lin(getattr(self, f"mlp_{s}_2"))
         n = b * h * w
-        L.check(lib.swf_linear_fwd(C.byref(l1), _ptr(tn), None, _ptr(hid), n, c, self.hidden_dims, 1, _stream(t.device)))
-        L.check(lib.swf_linear_fwd(C.byref(l2), _ptr(hid), None, _ptr(out), n, self.hidden_dims, c, 0, _stream(t.device)))
+        prec = _precision_code(self.precision)
+        ws, wsn = _workspace(max(lib.swf_linear_workspace_bytes(prec, n, c, self.hidden_dims),
+                                 lib.swf_linear_workspace_bytes(prec, n, self.hidden_dims, c)), t.device)
+        L.check(lib.swf_linear_fwd_prec(C.byref(l1), prec, _ptr(tn), None, _ptr(hid), n, c, self.hidden_dims, 1, ws, wsn, _stream(t.device)))
+        L.check(lib.swf_linear_fwd_prec(C.byref(l2), prec, _ptr(hid), None, _ptr(out), n, self.hidden_dims, c, 0, ws, wsn, _stream(t.device)))
         return _to_nchw(out)
 
     def forward(self, x, y):
@@ -289,6 +301,7 @@ class AddAndLayerNormWithOtherModule(_FwdAlias, nn.Module):
     def __init__(self, normalized_shape: list, use_dual_path: bool, other_module: nn.Module):
         super().__init__()
         self.normalized_shape, self.use_dual_path, self.other_module = normalized_shape, use_dual_path, other_module
+        self.precision = "fast"
         self.norm_layer_1 = nn.LayerNorm(normalized_shape=normalized_shape)
         if use_dual_path:
             self.norm_layer_2 = nn.LayerNorm(normalized_shape=normalized_shape)
@@ -303,11 +316,12 @@ class AddAndLayerNormWithOtherModule(_FwdAlias, nn.Module):
         oy = torch.empty_like(yn) if dual else None
         lib = L.lib()
         streams = ("x", "y") if dual else ("x",)
+        prec = _precision_code(self.precision)
         norms = {"x": self.norm_layer_1, "y": getattr(self, "norm_layer_2", None)}
         prm = {}
         if isinstance(om, AutoPathWinAtt):
             wa0 = om.window_attention_x
-            desc = L.BlockDesc(wa0._desc(), 1, int(bool(om.use_cross_att)), L.PREC_FP32)
+            desc = L.BlockDesc(wa0._desc(), 1, int(bool(om.use_cross_att)), prec)
             for s in streams:
                 p = L.BlockStreamParams()
                 p.ln1 = _norm(norms[s])
@@ -316,7 +330,7 @@ class AddAndLayerNormWithOtherModule(_FwdAlias, nn.Module):
             fn = lib.swf_attn_halfblock_fwd
         elif isinstance(om, AutoPathMLP):
             _require_elu(om.activation_func)
-            desc = L.BlockDesc(L.AttnDesc(om.in_out_dims, 1, 1, 1, 1, 0), om.hidden_dims, 0, L.PREC_FP32)
+            desc = L.BlockDesc(L.AttnDesc(om.in_out_dims, 1, 1, 1, 1, 0), om.hidden_dims, 0, prec)
             for s in streams:
                 p = L.BlockStreamParams()
                 p.ln2 = _norm(norms[s])
@@ -326,7 +340,7 @@ class AddAndLayerNormWithOtherModule(_FwdAlias, nn.Module):
         else:
             raise NotImplementedError("other_module must be AutoPathWinAtt or AutoPathMLP of this package")
         ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(
-            C.byref(L.BlockDesc(desc.attn, max(desc.hidden, 1), 0, L.PREC_FP32)), b, h, w), x.device)
+            C.byref(L.BlockDesc(desc.attn, max(desc.hidden, 1), 0, prec)), b, h, w), x.device)
         L.check(fn(C.byref(desc), C.byref(prm["x"]), C.byref(prm["y"]) if dual else None, _ptr(xn),
                    _ptr(yn) if dual else None, _ptr(ox), _ptr(oy) if dual else None, b, h, w, ws, wsn, _stream(x.device)))
         if dual:
@@ -369,8 +383,7 @@ class BasicBlock(_FwdAlias, nn.Module):
         ok = x is not None and (y is not None) == bool(self.use_dual_path)
         if ok and self.use_cross_attr and y is not None and torch.equal(x, y):
             ok = False
-        if not ok:
-            self.input_compatibility_with_cross_option = False
+        if not ok:   # stays None: every later call re-checks and raises again (the reference would have exited, a005:118)
             raise ValueError("inputs are incompatible with the cross_attr / dual_path options "
                              "(y missing or unexpected, or cross attention given identical x and y)")
         self.input_compatibility_with_cross_option = True
@@ -777,6 +790,9 @@ class MyModel(_FwdAlias, nn.Module):
 
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, in_x: Tensor, in_y: Tensor) -> Tensor:
+        """a013:209-230 as one C call.  The FIRST forward of a model (and every forward after a failed input check)
+        reads the per-block identical-streams flags back to the host (a005:98-118), so it synchronises and cannot be
+        captured into a hipGraph: run one eager forward first (shard.ShardedFusion does)."""
         _check_forward_only(self, in_x, in_y)
         if self.training:
             raise RuntimeError("MyModel's HIP path is the eval() forward (BatchNorm running statistics, "
@@ -802,7 +818,7 @@ class MyModel(_FwdAlias, nn.Module):
                                                   _stream(x.device)))
             same = flags.cpu().nonzero().flatten().tolist()
             if same:
-                self.input_compatibility_with_cross_option = False
+                # stays None: the next forward runs the check again (the reference would have exited here, a005:118)
                 n = len(self.in_dims_list)
                 where = [f"{'encoder' if i // 2 < n else 'decoder'}_list.{(i // 2) % n} cross block {i % 2}" for i in same]
                 raise ValueError("inputs are incompatible with the cross_attr option: cross attention received identical "

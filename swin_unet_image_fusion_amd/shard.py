@@ -76,6 +76,7 @@ class ShardedFusion:
         self._stage = [None, None]
         self._slot = 0
         self._cap_stream = None   # one capture stream for the runner's lifetime: the library workspace is keyed by stream
+        self._ws_ref = None       # the library workspace the captured graph points into: held so that nothing frees it
         self.captures = 0
 
     # -- forward of the local shard --------------------------------------------------------------
@@ -84,7 +85,7 @@ class ShardedFusion:
 
     def _capture(self, ir, vis):
         ir, vis = ir.clone(), vis.clone()             # runner-owned static buffers
-        self._graph = self._static = None             # drop the old graph before its buffers
+        self._graph = self._static = self._ws_ref = None   # drop the old graph before its buffers
         self.forward_fn(ir, vis)                      # warm-up: sizes the workspace, builds the arena, first-forward check
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
@@ -99,6 +100,15 @@ class ShardedFusion:
             with torch.cuda.graph(g, stream=s, capture_error_mode="thread_local"):
                 out = self.forward_fn(ir, vis)
         torch.cuda.current_stream(ir.device).wait_stream(s)
+        # The graph holds the raw address of the library workspace registered for (device, capture-stream handle).  That
+        # registry replaces (and so frees) a buffer when a later call on the same handle needs more bytes, and torch hands
+        # stream handles out of a 32-entry pool — another runner or model with a larger shape may land on this handle.
+        # Holding the tensor keeps the captured address valid for as long as this graph exists.
+        try:
+            from .modules import _workspace_tensor
+            self._ws_ref = _workspace_tensor(ir.device, s.cuda_stream)
+        except ImportError:       # forward_fn-only runners (tests on CPU) never get here: capture needs CUDA tensors
+            self._ws_ref = None
         self._graph, self._static, self.graph_active = g, (ir, vis, out), True
         self._key = (tuple(ir.shape), self._model_key())   # after the capture: the arena / packed images exist now
         self.captures += 1

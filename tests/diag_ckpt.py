@@ -1,27 +1,45 @@
-"""Where does the fast tier differ most from the oracle on the stress-weight 4-stage model? (diagnostic)"""
-import os, sys
+"""Diagnostic (not a test; run by hand on a GPU box: `python tests/diag_ckpt.py`): where does the fast tier differ most from the
+oracle on the stress-weight 4-stage model, and how uncertain is the reference's own fp32 answer there (fp32 vs fp64 oracle)?"""
+import os
+import sys
+
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import torch
-from torch import nn
-import __graft_entry__ as entry
-entry.build()
-from oracle import swin_fusion_oracle as O
-from swin_unet_image_fusion_amd import CONFIGS, MyModel, load_recipe_into, synthetic_pair
-torch.set_grad_enabled(False)
-cfg = CONFIGS["win8_4stage"]
-m = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True))).eval()
-load_recipe_into(m, seed=17, flavor="stress")
-sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-ir, vis = (torch.from_numpy(a) for a in synthetic_pair(2, 128, 128, seed_ir=21, seed_vis=22))
-ref = O.model_forward(sd, cfg, ir, vis)
-m.to("cuda:0")
-for prec in ("fp32", "fast"):
-    m.precision = prec
-    out = m(ir.cuda(), vis.cuda()).cpu()
-    err = (out - ref).abs()
-    print(prec, "rel-l2", float((out - ref).norm() / ref.norm()), "max-rel", float(err.max() / ref.abs().max()), "ref max", float(ref.abs().max()))
-    top = torch.topk(err.flatten(), 8)
-    for v, i in zip(top.values.tolist(), top.indices.tolist()):
-        b, rem = divmod(i, 128 * 128); y, x = divmod(rem, 128)
-        print(f"   err {v:.3e} at b={b} y={y} x={x}  out={float(out[b,0,y,x]):.5f} ref={float(ref[b,0,y,x]):.5f}")
-    print("   err quantiles", [float(torch.quantile(err.flatten(), q)) for q in (0.5, 0.9, 0.99, 0.999, 0.9999)])
+
+
+def main():
+    import torch
+    from torch import nn
+    import __graft_entry__ as entry
+    entry.build()
+    from oracle import swin_fusion_oracle as O
+    from swin_unet_image_fusion_amd import CONFIGS, MyModel, load_recipe_into, synthetic_pair
+    from tests import golden_util as G
+    torch.set_grad_enabled(False)
+    cfg = CONFIGS["win8_4stage"]
+    m = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True))).eval()
+    load_recipe_into(m, seed=17, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    ir, vis = (torch.from_numpy(a) for a in synthetic_pair(2, 128, 128, seed_ir=21, seed_vis=22))
+    ref, u, pooled, med = G.fp64_uncertainty(O.model_forward, sd, cfg, ir, vis)
+    print("fp32 oracle vs fp64 oracle: median %.3e max %.3e" % (med, float(u.max())))
+    m.to("cuda:0")
+    for prec in ("fp32", "fast"):
+        m.precision = prec
+        out = m(ir.cuda(), vis.cuda()).cpu()
+        err = (out - ref).abs()
+        print(prec, "rel-l2", float((out - ref).norm() / ref.norm()), "max-rel", float(err.max() / ref.abs().max()), "ref max", float(ref.abs().max()))
+        top = torch.topk(err.flatten(), 8)
+        for v, i in zip(top.values.tolist(), top.indices.tolist()):
+            b, rem = divmod(i, 128 * 128)
+            y, x = divmod(rem, 128)
+            print(f"   err {v:.3e} at b={b} y={y} x={x}  out={float(out[b, 0, y, x]):.5f} ref={float(ref[b, 0, y, x]):.5f}  fp32-vs-fp64 there {float(u[b, 0, y, x]):.2e}")
+        print("   err quantiles", [float(torch.quantile(err.flatten(), q)) for q in (0.5, 0.9, 0.99, 0.999, 0.9999)])
+        base = 1e-3 * float(ref.abs().max())
+        over = (err.double() > base).nonzero()
+        print(f"   pixels beyond 1e-3*max|ref| = {base:.3e}: {over.shape[0]}")
+        for b, _, y, x in over.tolist():
+            print(f"      b={b} y={y} x={x} err {float(err[b, 0, y, x]):.3e}  u {float(u[b, 0, y, x]):.2e}  pooled u {float(pooled[b, 0, y, x]):.2e} = {float(pooled[b, 0, y, x]) / med:.1f} x median")
+
+
+if __name__ == "__main__":
+    main()

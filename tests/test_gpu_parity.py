@@ -36,6 +36,8 @@ def _built():
     torch.set_grad_enabled(True)
     # per-fixture parity numbers of this run (copied into profiles/ by hand when they are to be judged)
     import json, os
+    if os.environ.get("SWF_PARITY_LOG") == "0":   # child runs of tests/test_gpu_switches.py must not overwrite the full record
+        return
     out_dir = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out")
     try:
         os.makedirs(out_dir, exist_ok=True)
@@ -72,16 +74,20 @@ def _elu():
     return nn.ELU(inplace=True)
 
 
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
 @pytest.mark.parametrize("name", G.cases("window_attention"))
-def test_window_attention(name):
+def test_window_attention(name, precision):
+    """a001:448-474 as a stand-alone module, both arithmetic tiers (swf_window_attention_fwd_prec)."""
     meta, arr = G.load(name)
     c = meta["ctor"]
     m = WindowAttention(**c).eval()
     load_recipe_into(m, seed=meta["weight_seed"], flavor=meta["flavor"])
     m.to(DEV)
+    m.precision = precision
     q = G.randn(meta["in_shape"], meta["seed_q"]).to(DEV)
     kv = G.randn(meta["in_shape"], meta["seed_kv"]).to(DEV) if c["use_cross_attention"] else q
-    _close(m(q, kv, kv), arr["expected"])
+    tol, tmax = (TOL_FP32, None) if precision == "fp32" else (TOL_FAST_L2, TOL_FAST_MAX)
+    _close(m(q, kv, kv), arr["expected"], tol, tmax)
     assert m.forward_(q, kv, kv).shape == q.shape
 
 
@@ -133,29 +139,35 @@ def test_normal_and_shift_block_pair(name, precision):
     assert torch.equal(fx, ox) and torch.equal(fy, oy)
 
 
-def test_inner_modules_compose_like_the_block():
+@pytest.mark.parametrize("precision", ["fp32", "fast"])
+def test_inner_modules_compose_like_the_block(precision):
     """AutoPathWinAtt / AutoPathMLP / AddAndLayerNormWithOtherModule (a002-a004) each have a HIP-backed
-    forward; composing them by hand reproduces BasicBlock (a005:138-141) and the golden vector."""
+    forward in both tiers; composing them by hand reproduces BasicBlock (a005:138-141) and the golden vector."""
     meta, arr = G.load("bb_cross_shift_w8")
     m = BasicBlock(**meta["ctor"], mlp_activation_func=_elu()).eval()
     load_recipe_into(m, seed=meta["weight_seed"], flavor=meta["flavor"])
     m.to(DEV)
+    for sub in m.modules():
+        if hasattr(sub, "precision"):
+            sub.precision = precision
+    tol = (TOL_FP32, None) if precision == "fp32" else (TOL_FAST_L2, TOL_FAST_MAX)
+    _close_ = lambda a, b: _close(a, b, *tol)
     x, y = G.randn(meta["in_shape"], meta["seed_x"]).to(DEV), G.randn(meta["in_shape"], meta["seed_y"]).to(DEV)
     assert isinstance(m.stage_1, AddAndLayerNormWithOtherModule) and isinstance(m.auto_path_win_att, AutoPathWinAtt)
     x1, y1 = m.stage_1(x, y)
     x2, y2 = m.stage_2(x1, y1)
-    _close(x2, arr["expected_x"]); _close(y2, arr["expected_y"])
+    _close_(x2, arr["expected_x"]); _close_(y2, arr["expected_y"])
     # the un-normed sub-modules against the oracle
     sd = {k: v.detach().cpu() for k, v in m.state_dict().items()}
     c = meta["ctor"]
     ax, ay = m.auto_path_win_att(x, y)
     rx, ry = O.auto_path_win_att(sd, "auto_path_win_att.", x.cpu(), y.cpu(), cross=True, num_heads=c["num_heads"],
                                  dims_per_head=c["dims_per_head"], window_size=tuple(c["window_size"]), use_cyclic_shift=True)
-    _close(ax, rx); _close(ay, ry)
+    _close_(ax, rx); _close_(ay, ry)
     assert isinstance(m.auto_path_mlp, AutoPathMLP)
     mx, my = m.auto_path_mlp(x, y)
     rx, ry = O.auto_path_mlp(sd, "auto_path_mlp.", x.cpu(), y.cpu())
-    _close(mx, rx); _close(my, ry)
+    _close_(mx, rx); _close_(my, ry)
 
 
 @pytest.mark.parametrize("name", G.cases("patch_layer"))
@@ -300,14 +312,17 @@ def test_reference_checkpoint_to_gpu_forward(tmp_path):
     extra = m.load_reference_checkpoint(str(path))
     assert extra["current_epoch"] == 3 and "optimizer_state" in extra
     ir, vis = (torch.from_numpy(a) for a in synthetic_pair(2, 128, 128, seed_ir=21, seed_vis=22))
-    ref = O.model_forward(sd, cfg, ir, vis)
-    # These stress weights (seed 17) put a patch of ill-conditioned tokens at (b=0, y 45..50, x 64..74): the exact tier's own
-    # largest errors sit on the same pixels, 60x its median error (tests/diag_ckpt.py: fp32 tier median 1.7e-7 / max 1.0e-5,
-    # fast tier median 2.8e-5 / max 1.6e-3, rel-L2 1.5e-4).  The max-error gate of this one case is therefore 5e-3; the
-    # rel-L2 gate stays at the north-star 1e-3.
-    for precision, tol in (("fp32", (5e-5, None)), ("fast", (TOL_FAST_L2, 5e-3))):
-        m.precision = precision
-        _close(m(ir.to(DEV), vis.to(DEV)), ref, *tol)
+    # These stress weights (seed 17) put a patch of ill-conditioned pixels at (b=0, y 45..48, x 64..66): the reference's own fp32
+    # answer differs from an fp64 evaluation by 5.5e-6 there, 44x its median (tests/diag_ckpt.py).  The max-error gate is the
+    # north star's 1e-3 of max|ref| plus C_ROUNDOFF x that measured fp32 uncertainty, and every pixel that needs the second term
+    # must be ill-conditioned by the fp64 measure (golden_util.close_conditioned); rel-L2 stays at 1e-3.
+    ref, u, pooled, med = G.fp64_uncertainty(O.model_forward, sd, cfg, ir, vis)
+    assert float(u.max()) >= G.K_ILL * med      # the conditioning story itself: the fp32 reference is that uncertain somewhere
+    m.precision = "fp32"
+    _close(m(ir.to(DEV), vis.to(DEV)), ref, 5e-5, None)
+    m.precision = "fast"
+    l2, mx, n_ill = G.close_conditioned(m(ir.to(DEV), vis.to(DEV)), ref, pooled, med, TOL_FAST_L2, TOL_FAST_MAX)
+    _PARITY_LOG.append((_CUR_TEST + "[fast, fp64-conditioned gate, %d pixels beyond 1e-3]" % n_ill, l2, mx))
 
 
 def _mirror_x_into_y(model):
@@ -339,9 +354,10 @@ def test_model_first_forward_identical_streams_guard():
     for precision in ("fp32", "fast"):
         m.precision = precision
         m.input_compatibility_with_cross_option = None
-        with pytest.raises(ValueError):
-            m(ir.to(DEV), ir.clone().to(DEV))
-        assert m.input_compatibility_with_cross_option is False
+        for _ in range(2):   # a failed check is not remembered: the same bad inputs raise again on the next call
+            with pytest.raises(ValueError):
+                m(ir.to(DEV), ir.clone().to(DEV))
+            assert m.input_compatibility_with_cross_option is None
     # distinct inputs pass the check once, later forwards skip it (as the reference does)
     ok = MyModel(**cfg.model_kwargs(_elu())).eval()
     load_recipe_into(ok, seed=5, flavor="stress")
@@ -530,6 +546,28 @@ def test_basic_block_window7_fast_vs_oracle(case):
     _close(oy, ry, TOL_FAST_L2, TOL_FAST_MAX)
     ox2, oy2 = m(x.to(DEV), y.to(DEV))
     assert torch.equal(ox, ox2) and torch.equal(oy, oy2)
+
+
+def test_fused_block_beyond_2gb_runs_in_batch_slices():
+    """The register-resident block kernels address a stream's map through 32-bit buffer offsets: a map of 2^31 bytes or more is
+    launched in batch slices (kernels_window.hip: launch_window_block).  B=22 at C=96 on a 512x512 map is 2.2 GB per stream =
+    slices of 21 + 1 images; images are independent, so every image must equal — bit for bit — the same image run alone."""
+    c, nh, d, hid, b, h, w = 96, 8, 12, 384, 22, 512, 512
+    assert b * h * w * c * 4 >= 2 ** 31 and 21 * h * w * c * 4 < 2 ** 31
+    m = BasicBlock(c, nh, d, (8, 8), True, True, True, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
+    load_recipe_into(m, seed=29, flavor="stress")
+    m.to(DEV)
+    m.precision = "fast"
+    g = torch.Generator(device=DEV).manual_seed(5)
+    x = torch.randn((b, c, h, w), device=DEV, generator=g)
+    y = torch.randn((b, c, h, w), device=DEV, generator=g)
+    ox, oy = m(x, y)
+    assert bool(torch.isfinite(ox).all()) and bool(torch.isfinite(oy).all())
+    for i in (0, 20, 21):   # first image, last image of the first slice, the image of the second slice
+        sx, sy = m(x[i:i + 1].contiguous(), y[i:i + 1].contiguous())
+        assert torch.equal(ox[i:i + 1], sx) and torch.equal(oy[i:i + 1], sy), i
+    del x, y, ox, oy
+    torch.cuda.empty_cache()
 
 
 def test_block_prepack_matches_per_call_pack():

@@ -1,15 +1,17 @@
 """Fast-tier forward against the CPU oracle on odd shapes (ragged maps, small batches, all three window sizes), and repeated forwards
 that must equal the first bit for bit.  Sizes keep every reflect pad smaller than its map, as the reference requires (a006:128).
 
-Last build: rel-L2 3.3e-5 ... 1.4e-4 on the nine shapes.  The largest max-error (1.3e-3 of max|ref| at B=1 160x192, seed-3 weights) sits
-on one ill-conditioned pixel where the exact fp32 tier also has its largest error (5e-6, 50x its median); the same case measured
-1.5e-3 with the kernels of the start of round 2 — hence the 5e-3 max gate here, next to the north star's 1e-3 on rel-L2."""
+Gates: rel-L2 <= 1e-3 and max|err| <= 1e-3 of max|ref| (north star).  One case (B=1 160x192, seed-3 weights) holds a patch of
+ill-conditioned pixels (y 69..71, x 129..132) where the reference's own fp32 answer is 5.3e-6 away from an fp64 evaluation, 67x the
+median: a shape that misses the plain max gate is re-checked against the fp64-derived bound of golden_util.close_conditioned
+(1e-3*max|ref| + 2^8 x the measured fp32 uncertainty, and only at pixels the fp64 measure calls ill-conditioned)."""
 import pytest
 import torch
 from torch import nn
 
 from oracle import swin_fusion_oracle as O
 from swin_unet_image_fusion_amd import CONFIGS, MyModel, load_recipe_into, synthetic_pair
+from tests import golden_util as G
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
@@ -32,7 +34,12 @@ def test_odd_shapes_fast_tier_vs_oracle(cfg_name, b, h, w):
     got = model(ir.to(DEV), vis.to(DEV)).cpu()
     l2 = float((got - ref).norm() / ref.norm())
     mx = float((got - ref).abs().max() / ref.abs().max())
-    assert l2 <= 1e-3 and mx <= 5e-3, (l2, mx)
+    assert l2 <= 1e-3, (l2, mx)
+    if mx > 1e-3:   # only with fp64 evidence that the offending pixels are ill-conditioned in the reference itself
+        ref32, u, pooled, med = G.fp64_uncertainty(O.model_forward, sd, cfg, ir, vis)
+        assert torch.equal(ref32, ref)
+        _, _, n_ill = G.close_conditioned(got, ref, pooled, med, 1e-3, 1e-3)
+        print(f"{cfg_name} b{b} {h}x{w}: max-rel {mx:.2e} on {n_ill} ill-conditioned pixels (fp32-vs-fp64 {float(u.max()):.2e}, median {med:.2e})")
 
 
 @pytest.mark.parametrize("cfg_name,b,size", [("win8", 16, 256), ("win7", 16, 224), ("win8", 5, 512), ("win16", 2, 1024), ("win8", 3, 320)])

@@ -12,7 +12,15 @@
 using namespace swf;
 #define CK(x) do { hipError_t e = (x); if (e != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e), __LINE__); return 1; } } while (0)
 
+// MLP_PROBE_COLD=1: a 768 MB memset between launches evicts L2 / Infinity Cache (weights and rows then come from HBM, as they do
+// inside a forward).  MLP_PROBE_FOLD=1: the attention tail (x + proj bias + two partials -> x1) in the prologue and the next
+// block's LN1 planes from the epilogue / reduce, as the level-3 blocks run it inside the model.
 int main() {
+    const bool cold = getenv("MLP_PROBE_COLD") != nullptr, fold = getenv("MLP_PROBE_FOLD") != nullptr;
+    char* evict = nullptr;
+    const size_t evict_bytes = size_t(768) << 20;
+    if (cold) CK(hipMalloc(&evict, evict_bytes));
+    printf("== cold=%d fold=%d\n", (int)cold, (int)fold);
     struct Shape { const char* name; int M, C, HID; } shapes[] = {{"L3 enc", 4096, 192, 768}, {"L3 dec", 4096, 192, 384}, {"L4 enc", 1024, 384, 1536}, {"L4 dec", 1024, 384, 768}};
     hipStream_t st;
     CK(hipStreamCreate(&st));
@@ -32,17 +40,30 @@ int main() {
             d.b1[s] = b1; d.b2[s] = b2;
         }
         d.scratch = scratch; d.scratch_floats = (int64_t)xe * 2 * S; d.M = sh.M; d.C = sh.C; d.HID = sh.HID;
+        float* extra[2][3]; bf16_raw* lnp[2][2];
+        if (fold)
+            for (int s = 0; s < 2; ++s) {
+                for (int i = 0; i < 3; ++i) { CK(hipMalloc(&extra[s][i], xe * 4)); CK(hipMemset(extra[s][i], 0, xe * 4)); }
+                for (int i = 0; i < 2; ++i) CK(hipMalloc(&lnp[s][i], xe * 2));
+                d.part0[s] = extra[s][0]; d.part1[s] = extra[s][1]; d.x1[s] = extra[s][2]; d.pbias[s] = b2;
+                d.ln_gamma[s] = g; d.ln_beta[s] = b; d.ln_hi[s] = lnp[s][0]; d.ln_lo[s] = lnp[s][1];
+            }
         for (int it = 0; it < 3; ++it)
             if (launch_mlp_fused(d, 2, st) != SWF_OK) { printf("launch failed: %s\n", swf_last_error_string()); return 1; }
         CK(hipStreamSynchronize(st));
         hipEvent_t e0, e1;
         CK(hipEventCreate(&e0)); CK(hipEventCreate(&e1));
-        CK(hipEventRecord(e0, st));
-        for (int it = 0; it < 10; ++it) launch_mlp_fused(d, 2, st);
-        CK(hipEventRecord(e1, st));
-        CK(hipStreamSynchronize(st));
         float ms = 0.f;
-        CK(hipEventElapsedTime(&ms, e0, e1));
+        for (int it = 0; it < 10; ++it) {
+            if (cold) CK(hipMemsetAsync(evict, it, evict_bytes, st));
+            CK(hipEventRecord(e0, st));
+            launch_mlp_fused(d, 2, st);
+            CK(hipEventRecord(e1, st));
+            CK(hipStreamSynchronize(st));
+            float t = 0.f;
+            CK(hipEventElapsedTime(&t, e0, e1));
+            ms += t;
+        }
         unsigned long long h[64];
         CK(hipMemcpyFromSymbol(h, HIP_SYMBOL(swf_mlp_probe), sizeof(h)));
         {   // every workgroup's entry / exit, relative to the first entry (last launch)
