@@ -67,27 +67,37 @@ __device__ __forceinline__ void mma3(f32x16& acc, const bf16x8 wh, const bf16x8 
 // NW waves per workgroup = a hidden chunk of CW = 32 NW.  NW = 8 (C = 384): two waves per SIMD, each streaming its own fragments
 // (the per-wave vector-memory rate, not L2, bounds the 4-wave kernel: DESIGN A.3), ONE 256-wide chunk per workgroup with the H image
 // laid over the A image once fc1 has read it (A + H side by side would need 168 KB).
-template <int C, int NW>
+// TOK = token rows per workgroup (64, or 32 with NW = 6 at C = 192: twice the workgroups for the same weight bytes each — the level-3
+// launches fill 128-256 of the 256 CUs with 64-token tiles, and a workgroup's prologue / epilogue rows are private HBM / MALL round
+// trips that only more workgroups hide).
+template <int C, int NW, int TOK = 64>
 __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
-    constexpr int NT = 64 * NW, CW = 32 * NW, TPR = NT / 64;   // threads, hidden chunk width, threads per token row
+    constexpr int NT = 64 * NW, CW = 32 * NW;    // threads, hidden chunk width
+    constexpr int NTT = TOK / 32;                // 32-token tiles per workgroup
+    static_assert(TOK == 32 || TOK == 64, "token tile");
+    // threads per token row in the LayerNorm prologue / the row epilogue: a power of two, rows never straddle a wave
+    constexpr int TPR = (NT / TOK == 4 || NT / TOK == 8) ? NT / TOK : 8;
+    constexpr int LNT = TOK * TPR;               // threads that own a piece of a row (the rest only stream weights meanwhile)
+    static_assert(LNT <= NT, "row threads");
     constexpr int KS1 = C / 16;                  // k16 steps of fc1
     constexpr int T = C / 32;                    // 32-channel output tiles of fc2
     constexpr int NF = T / NW, R = T % NW;       // whole tiles per wave; the R left-over tiles are dealt as 2R halves
     static_assert(R == 0 || 2 * R == NW, "the left-over output tiles must deal out as one half tile per wave");
+    static_assert(R == 0 || NTT == 2, "half tiles need two token halves");
     constexpr int NH = R ? 1 : 0;                // + one half tile (one 32-token half)
     constexpr int NFR = NF + NH;                 // W2 fragments per k16 step
     constexpr int KS2 = CW / 16;                 // k16 steps per hidden chunk
     constexpr int NFRAG = KS1 + KS2 * NFR;       // weight fragments a wave streams per chunk
-    constexpr int D = NW == 8 ? 8 : (NFRAG % 16 == 0) ? 16 : 14;   // ring depth: ~1 us of MFMA work ahead (L2 / MALL latency under load)
+    constexpr int D = NW == 8 ? 8 : (NFRAG % 16 == 0) ? 16 : (NFRAG % 14 == 0) ? 14 : 12;   // ring depth: ~1 us of MFMA work ahead (L2 / MALL latency under load)
     static_assert(NFRAG % D == 0, "ring depth must divide the fragment count");
     constexpr bool ALIAS = NW == 8;              // H over A: one chunk per workgroup (launch_c checks)
     constexpr int LDA = C + 8, LDH = CW + 8;     // row strides (bf16): odd multiples of 16 B
     static_assert(!ALIAS || LDH <= LDA, "the H image must fit the A image");
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     bf16* a_hi = reinterpret_cast<bf16*>(smem);
-    bf16* a_lo = a_hi + 64 * LDA;
-    bf16* h_hi = ALIAS ? a_hi : a_lo + 64 * LDA;
-    bf16* h_lo = h_hi + 64 * LDH;
+    bf16* a_lo = a_hi + TOK * LDA;
+    bf16* h_hi = ALIAS ? a_hi : a_lo + TOK * LDA;
+    bf16* h_lo = h_hi + TOK * LDH;
 
     const int tile = blockIdx.x, split = blockIdx.y, s = blockIdx.z;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -133,76 +143,89 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
     //      rows (and gamma / beta, which travel through the idle H buffer) are requested BEFORE the weight ring's first D
     //      fragments: the ring then fills during the LayerNorm arithmetic instead of delaying it (3.1 -> 1.x us at C=192). ----
     {
-        const int row = tid / TPR, sub = tid % TPR;
-        const int m = min(tile * 64 + row, a.M - 1);   // rows past M are computed on a clamped copy and never stored
+        const bool rowt = tid < LNT;   // this thread owns a piece of a token row
+        const int row = rowt ? tid / TPR : 0, sub = tid % TPR;
+        const int m = min(tile * TOK + row, a.M - 1);   // rows past M are computed on a clamped copy and never stored
         const float* xr = a.x[s] + (int64_t)m * C;
         constexpr int NV = C / (4 * TPR), CS = 4 * TPR;   // float4s per thread, column step
         float4 v[NV];
+        if (rowt) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + CS * i + 4 * sub);
-        if (a.part0[s]) {   // attention residual: x + proj bias + the two head-group partials of the projection, fixed order
-            const float* p0 = a.part0[s] + (int64_t)m * C;
-            const float* p1 = a.part1[s] + (int64_t)m * C;
-            float4 u0[NV], u1[NV];
+            for (int i = 0; i < NV; ++i) v[i] = *reinterpret_cast<const float4*>(xr + CS * i + 4 * sub);
+            if (a.part0[s]) {   // attention residual: x + proj bias + the two head-group partials of the projection, fixed order
+                const float* p0 = a.part0[s] + (int64_t)m * C;
+                const float* p1 = a.part1[s] + (int64_t)m * C;
+                float4 u0[NV], u1[NV], pb[NV];
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                u0[i] = *reinterpret_cast<const float4*>(p0 + CS * i + 4 * sub);
-                u1[i] = *reinterpret_cast<const float4*>(p1 + CS * i + 4 * sub);
-            }
-            const bool wr = split == 0 && tile * 64 + row < a.M;
+                for (int i = 0; i < NV; ++i) {
+                    u0[i] = *reinterpret_cast<const float4*>(p0 + CS * i + 4 * sub);
+                    u1[i] = *reinterpret_cast<const float4*>(p1 + CS * i + 4 * sub);
+                    pb[i] = *reinterpret_cast<const float4*>(a.pbias[s] + CS * i + 4 * sub);
+                }
+                const bool wr = split == 0 && tile * TOK + row < a.M;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
-                const float4 pb = *reinterpret_cast<const float4*>(a.pbias[s] + CS * i + 4 * sub);
-                v[i].x = ((v[i].x + pb.x) + u0[i].x) + u1[i].x; v[i].y = ((v[i].y + pb.y) + u0[i].y) + u1[i].y;
-                v[i].z = ((v[i].z + pb.z) + u0[i].z) + u1[i].z; v[i].w = ((v[i].w + pb.w) + u0[i].w) + u1[i].w;
-                if (wr) *reinterpret_cast<float4*>(a.x1[s] + (int64_t)m * C + CS * i + 4 * sub) = v[i];
+                for (int i = 0; i < NV; ++i) {
+                    v[i].x = ((v[i].x + pb[i].x) + u0[i].x) + u1[i].x; v[i].y = ((v[i].y + pb[i].y) + u0[i].y) + u1[i].y;
+                    v[i].z = ((v[i].z + pb[i].z) + u0[i].z) + u1[i].z; v[i].w = ((v[i].w + pb[i].w) + u0[i].w) + u1[i].w;
+                    if (wr) *reinterpret_cast<float4*>(a.x1[s] + (int64_t)m * C + CS * i + 4 * sub) = v[i];
+                }
             }
         }
-        float* gb = reinterpret_cast<float*>(ALIAS ? a_lo + 64 * LDA : h_hi);   // [2][C] fp32: gamma, beta
+        SWF_PROBE(50);
+        float* gb = reinterpret_cast<float*>(ALIAS ? a_lo + TOK * LDA : h_hi);   // [2][C] fp32: gamma, beta
         float4 gbv = make_float4(0.f, 0.f, 0.f, 0.f);
         if (tid < C / 2) gbv = *reinterpret_cast<const float4*>((tid < C / 4 ? a.gamma[s] : a.beta[s] - C) + 4 * tid);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int f = 0; f < D; ++f) frag_load(f, hb0);   // the ring's first fragments: in flight during the LayerNorm arithmetic
         __builtin_amdgcn_sched_barrier(0);
+        SWF_PROBE(51);
         if (tid < C / 2) *reinterpret_cast<float4*>(gb + 4 * tid) = gbv;
-        float sum = 0.f;
+        SWF_PROBE(52);
+        float mean = 0.f, rstd = 0.f;
+        if (rowt) {
+            float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
-        sum += __shfl_xor(sum, 1);
-        sum += __shfl_xor(sum, 2);
-        if constexpr (TPR == 8) sum += __shfl_xor(sum, 4);
-        const float mean = sum * (1.0f / C);
-        float var = 0.f;
+            for (int i = 0; i < NV; ++i) sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+            sum += __shfl_xor(sum, 1);
+            sum += __shfl_xor(sum, 2);
+            if constexpr (TPR == 8) sum += __shfl_xor(sum, 4);
+            mean = sum * (1.0f / C);
+            float var = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
-            var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            for (int i = 0; i < NV; ++i) {
+                const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
+                var += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
+            }
+            var += __shfl_xor(var, 1);
+            var += __shfl_xor(var, 2);
+            if constexpr (TPR == 8) var += __shfl_xor(var, 4);
+            rstd = 1.0f / sqrtf(var * (1.0f / C) + 1e-5f);
         }
-        var += __shfl_xor(var, 1);
-        var += __shfl_xor(var, 2);
-        if constexpr (TPR == 8) var += __shfl_xor(var, 4);
-        const float rstd = 1.0f / sqrtf(var * (1.0f / C) + 1e-5f);
+        SWF_PROBE(53);
         __syncthreads();   // gamma / beta are in LDS
+        SWF_PROBE(54);
+        if (rowt) {
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = CS * i + 4 * sub;
-            const float4 gm = *reinterpret_cast<const float4*>(gb + c), bt = *reinterpret_cast<const float4*>(gb + C + c);
-            const float n[4] = {(v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y,
-                                (v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w};
-            bf16x4 h, l;
+            for (int i = 0; i < NV; ++i) {
+                const int c = CS * i + 4 * sub;
+                const float4 gm = *reinterpret_cast<const float4*>(gb + c), bt = *reinterpret_cast<const float4*>(gb + C + c);
+                const float n[4] = {(v[i].x - mean) * rstd * gm.x + bt.x, (v[i].y - mean) * rstd * gm.y + bt.y,
+                                    (v[i].z - mean) * rstd * gm.z + bt.z, (v[i].w - mean) * rstd * gm.w + bt.w};
+                bf16x4 h, l;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) { h[j] = (bf16)n[j]; l[j] = (bf16)(n[j] - (float)h[j]); }
-            *reinterpret_cast<bf16x4*>(a_hi + row * LDA + c) = h;
-            *reinterpret_cast<bf16x4*>(a_lo + row * LDA + c) = l;
+                for (int j = 0; j < 4; ++j) { h[j] = (bf16)n[j]; l[j] = (bf16)(n[j] - (float)h[j]); }
+                *reinterpret_cast<bf16x4*>(a_hi + row * LDA + c) = h;
+                *reinterpret_cast<bf16x4*>(a_lo + row * LDA + c) = l;
+            }
         }
     }
     __syncthreads();
     SWF_PROBE(1);
 
-    f32x16 acc2[2 * NF + NH];
+    f32x16 acc2[NTT * NF + NH];
 #pragma unroll
-    for (int i = 0; i < 2 * NF + NH; ++i)
+    for (int i = 0; i < NTT * NF + NH; ++i)
 #pragma unroll
         for (int e = 0; e < 16; ++e) acc2[i][e] = 0.f;
 
@@ -212,9 +235,11 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
         // fragments (dead loads) instead of branching: a conditional prefetch costs the counted waits their count
         const int hbn = ch + 1 < a.nchunks ? hb + CW : hb;
         // ---- fc1: H^T[32 hidden of this wave][64 tokens] ----
-        f32x16 acc1[2];
+        f32x16 acc1[NTT];
 #pragma unroll
-        for (int e = 0; e < 16; ++e) { acc1[0][e] = 0.f; acc1[1][e] = 0.f; }
+        for (int t = 0; t < NTT; ++t)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc1[t][e] = 0.f;
         // the chunk's fc1 bias goes out FIRST: vmcnt retires in order, so a bias load issued after the weight prefetches
         // would drain the whole ring at the phase boundary
         float4 b1v[4];
@@ -223,33 +248,41 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
         __builtin_amdgcn_sched_barrier(0);
         // B fragments (tokens) are read one k16 step ahead of their MFMAs: the scheduling fences below pin the order
         // [ring prefetch, next step's LDS reads] -> [this step's MFMAs], so LDS latency hides behind the matrix work
-        bf16x8 bh0, bl0, bh1, bl1;
+        bf16x8 bh[2], bl[2];   // [token tile] (NTT of them live)
         {
             const int ko = 8 * hf;
-            bh0 = *reinterpret_cast<const bf16x8*>(a_hi + r * LDA + ko); bl0 = *reinterpret_cast<const bf16x8*>(a_lo + r * LDA + ko);
-            bh1 = *reinterpret_cast<const bf16x8*>(a_hi + (32 + r) * LDA + ko); bl1 = *reinterpret_cast<const bf16x8*>(a_lo + (32 + r) * LDA + ko);
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) {
+                bh[t] = *reinterpret_cast<const bf16x8*>(a_hi + (32 * t + r) * LDA + ko);
+                bl[t] = *reinterpret_cast<const bf16x8*>(a_lo + (32 * t + r) * LDA + ko);
+            }
         }
 #pragma unroll
         for (int f = 0; f < KS1; ++f) {
             const bf16x8 wh = rh[f % D], wl = rl[f % D];
             if (f + D < NFRAG) frag_load(f + D, hb);
             else frag_load(f + D - NFRAG, hbn);
-            const bf16x8 ch0 = bh0, cl0 = bl0, ch1 = bh1, cl1 = bl1;
+            bf16x8 ch_[2], cl_[2];
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) { ch_[t] = bh[t]; cl_[t] = bl[t]; }
             if (f + 1 < KS1) {
                 const int ko = 16 * (f + 1) + 8 * hf;
-                bh0 = *reinterpret_cast<const bf16x8*>(a_hi + r * LDA + ko); bl0 = *reinterpret_cast<const bf16x8*>(a_lo + r * LDA + ko);
-                bh1 = *reinterpret_cast<const bf16x8*>(a_hi + (32 + r) * LDA + ko); bl1 = *reinterpret_cast<const bf16x8*>(a_lo + (32 + r) * LDA + ko);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    bh[t] = *reinterpret_cast<const bf16x8*>(a_hi + (32 * t + r) * LDA + ko);
+                    bl[t] = *reinterpret_cast<const bf16x8*>(a_lo + (32 * t + r) * LDA + ko);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);   // keep the prefetch D fragments ahead: hipcc otherwise sinks it next to its use
-            mma3(acc1[0], wh, wl, ch0, cl0);
-            mma3(acc1[1], wh, wl, ch1, cl1);
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) mma3(acc1[t], wh, wl, ch_[t], cl_[t]);
             __builtin_amdgcn_sched_barrier(0);
         }
         SWF_PROBE(2 + 4 * (ch & 7));
         if constexpr (ALIAS) __syncthreads();   // every wave has read its last A fragments: the H image may overwrite them
         // bias, ELU, split: register 4g+j of token half t is hidden 32w + 8g + 4hf + j of token 32t + r
 #pragma unroll
-        for (int t = 0; t < 2; ++t)
+        for (int t = 0; t < NTT; ++t)
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
                 const int hl = 32 * wave + 8 * g + 4 * hf;
@@ -270,8 +303,11 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
         {
             const int ko = 8 * hf;
             if constexpr (NF > 0) {
-                bh0 = *reinterpret_cast<const bf16x8*>(h_hi + r * LDH + ko); bl0 = *reinterpret_cast<const bf16x8*>(h_lo + r * LDH + ko);
-                bh1 = *reinterpret_cast<const bf16x8*>(h_hi + (32 + r) * LDH + ko); bl1 = *reinterpret_cast<const bf16x8*>(h_lo + (32 + r) * LDH + ko);
+#pragma unroll
+                for (int t = 0; t < NTT; ++t) {
+                    bh[t] = *reinterpret_cast<const bf16x8*>(h_hi + (32 * t + r) * LDH + ko);
+                    bl[t] = *reinterpret_cast<const bf16x8*>(h_lo + (32 * t + r) * LDH + ko);
+                }
             }
             if constexpr (NH) {
                 xh = *reinterpret_cast<const bf16x8*>(h_hi + (32 * half_tok + r) * LDH + ko);
@@ -288,12 +324,18 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
                 if (f + D < NFRAG) frag_load(f + D, hb);
                 else frag_load(f + D - NFRAG, hbn);
             }
-            const bf16x8 ch0 = bh0, cl0 = bl0, ch1 = bh1, cl1 = bl1, cxh = xh, cxl = xl;
+            bf16x8 ch_[2], cl_[2];
+#pragma unroll
+            for (int t = 0; t < NTT; ++t) { ch_[t] = bh[t]; cl_[t] = bl[t]; }
+            const bf16x8 cxh = xh, cxl = xl;
             if (ks + 1 < KS2) {
                 const int ko = 16 * (ks + 1) + 8 * hf;
                 if constexpr (NF > 0) {
-                    bh0 = *reinterpret_cast<const bf16x8*>(h_hi + r * LDH + ko); bl0 = *reinterpret_cast<const bf16x8*>(h_lo + r * LDH + ko);
-                    bh1 = *reinterpret_cast<const bf16x8*>(h_hi + (32 + r) * LDH + ko); bl1 = *reinterpret_cast<const bf16x8*>(h_lo + (32 + r) * LDH + ko);
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) {
+                        bh[t] = *reinterpret_cast<const bf16x8*>(h_hi + (32 * t + r) * LDH + ko);
+                        bl[t] = *reinterpret_cast<const bf16x8*>(h_lo + (32 * t + r) * LDH + ko);
+                    }
                 }
                 if constexpr (NH) {
                     xh = *reinterpret_cast<const bf16x8*>(h_hi + (32 * half_tok + r) * LDH + ko);
@@ -304,10 +346,10 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
             for (int j = 0; j < NFR; ++j) {
                 if (j < NF) {
-                    mma3(acc2[2 * j], wh[j], wl[j], ch0, cl0);
-                    mma3(acc2[2 * j + 1], wh[j], wl[j], ch1, cl1);
+#pragma unroll
+                    for (int t = 0; t < NTT; ++t) mma3(acc2[NTT * j + t], wh[j], wl[j], ch_[t], cl_[t]);
                 } else {
-                    mma3(acc2[2 * NF], wh[j], wl[j], cxh, cxl);
+                    mma3(acc2[NTT * NF], wh[j], wl[j], cxh, cxl);
                 }
             }
             __builtin_amdgcn_sched_barrier(0);
@@ -321,60 +363,80 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
     //      through the (now free) A image as fp32 rows and leaves as whole rows: consecutive lanes = consecutive channels
     //      (per-lane 16-byte stores at a row stride took 3-5 us here). ----
     constexpr int ORS = C + 4;   // row stride (floats): odd multiple of 16 B
-    static_assert(64 * ORS * 4 <= 2 * 64 * LDA * 2, "out tile must fit the A image");
+    static_assert(TOK * ORS * 4 <= 2 * TOK * LDA * 2, "out tile must fit the A image");
     float* otile = reinterpret_cast<float*>(smem);
+    float* part = a.splits > 1 ? a.scratch + ((int64_t)(s * a.splits + split) * a.M) * C : nullptr;
+    // unsplit: the rows are final here.  TPR threads per token row, so the NEXT block's LN1 (optional) is a shuffle reduction over the
+    // finished row and leaves as split planes from the same registers: no LayerNorm launch.  Everything the row epilogue reads from
+    // global memory (residual row, fc2 bias, the next LayerNorm's gamma / beta) is requested HERE, ahead of the out-tile exchange:
+    // cold parameter vectors cost a full HBM round trip each when they are requested where they are used (tools/mlp_probe.hip).
+    const int erow = tid < LNT ? tid / TPR : 0, esub = tid % TPR;
+    const int em = tile * TOK + erow;
+    const bool live = !part && em < a.M && tid < LNT;
+    constexpr int ENV = C / (4 * TPR), ECS = 4 * TPR;
+    float4 exr[ENV], eb2[ENV], eg[ENV], ebt[ENV];
+    const bool ln_out = !part && a.ln_hi[s] != nullptr;
+    if (live) {
+        const float* xres = (a.part0[s] ? a.x1[s] : a.x[s]) + (int64_t)em * C;   // (x1 holds this very thread's prologue stores: same mapping)
 #pragma unroll
-    for (int i = 0; i < 2 * NF + NH; ++i) {
-        const int nt = i < 2 * NF ? wave + NW * (i >> 1) : half_nt;
-        const int t = i < 2 * NF ? (i & 1) : half_tok;
+        for (int i = 0; i < ENV; ++i) {
+            const int c = ECS * i + 4 * esub;
+            exr[i] = *reinterpret_cast<const float4*>(xres + c);
+            eb2[i] = *reinterpret_cast<const float4*>(a.b2[s] + c);
+        }
+        if (ln_out) {
+#pragma unroll
+            for (int i = 0; i < ENV; ++i) {
+                const int c = ECS * i + 4 * esub;
+                eg[i] = *reinterpret_cast<const float4*>(a.ln_gamma[s] + c);
+                ebt[i] = *reinterpret_cast<const float4*>(a.ln_beta[s] + c);
+            }
+        }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int i = 0; i < NTT * NF + NH; ++i) {
+        const int nt = i < NTT * NF ? wave + NW * (i / NTT) : half_nt;
+        const int t = i < NTT * NF ? (i % NTT) : half_tok;
 #pragma unroll
         for (int g = 0; g < 4; ++g)
             *reinterpret_cast<float4*>(otile + (32 * t + r) * ORS + 32 * nt + 8 * g + 4 * hf) =
                 make_float4(acc2[i][4 * g], acc2[i][4 * g + 1], acc2[i][4 * g + 2], acc2[i][4 * g + 3]);
     }
     __syncthreads();
-    float* part = a.splits > 1 ? a.scratch + ((int64_t)(s * a.splits + split) * a.M) * C : nullptr;
     constexpr int C4 = C / 4;
     if (part) {
 #pragma unroll 4
-        for (int idx = tid; idx < 64 * C4; idx += NT) {
+        for (int idx = tid; idx < TOK * C4; idx += NT) {
             const int row = idx / C4, c = (idx % C4) * 4;
-            const int m = tile * 64 + row;
+            const int m = tile * TOK + row;
             if (m >= a.M) continue;
             *reinterpret_cast<float4*>(part + (int64_t)m * C + c) = *reinterpret_cast<const float4*>(otile + row * ORS + c);
         }
     } else {
-        // unsplit: the rows are final here.  4 threads per token row (64-byte segments), so the NEXT block's LN1 (optional) is a
-        // two-shuffle reduction over the finished row and leaves as split planes from the same registers: no LayerNorm launch
-        const int row = tid / TPR, sub = tid % TPR;
-        const int m = tile * 64 + row;
-        const bool live = m < a.M;
-        constexpr int NV = C / (4 * TPR), CS = 4 * TPR;
-        float4 v[NV];
+        float4 v[ENV];
         float sum = 0.f;
 #pragma unroll
-        for (int i = 0; i < NV; ++i) {
-            const int c = CS * i + 4 * sub;
+        for (int i = 0; i < ENV; ++i) {
+            const int c = ECS * i + 4 * esub;
             v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (live) {
-                float4 t = *reinterpret_cast<const float4*>(otile + row * ORS + c);
-                const float4 b = *reinterpret_cast<const float4*>(a.b2[s] + c);
-                // (with the attention tail fused, x1 holds this very thread's prologue stores: same row / column mapping)
-                const float4 x = *reinterpret_cast<const float4*>((a.part0[s] ? a.x1[s] : a.x[s]) + (int64_t)m * C + c);
+                float4 t = *reinterpret_cast<const float4*>(otile + erow * ORS + c);
+                const float4 b = eb2[i], x = exr[i];
                 t.x += b.x + x.x; t.y += b.y + x.y; t.z += b.z + x.z; t.w += b.w + x.w;
-                *reinterpret_cast<float4*>(a.out[s] + (int64_t)m * C + c) = t;
+                *reinterpret_cast<float4*>(a.out[s] + (int64_t)em * C + c) = t;
                 v[i] = t;
             }
             sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
         }
-        if (a.ln_hi[s]) {
+        if (ln_out) {
             sum += __shfl_xor(sum, 1);
             sum += __shfl_xor(sum, 2);
             if constexpr (TPR == 8) sum += __shfl_xor(sum, 4);
             const float mean = sum * (1.0f / C);
             float q = 0.f;
 #pragma unroll
-            for (int i = 0; i < NV; ++i) {
+            for (int i = 0; i < ENV; ++i) {
                 const float d0 = v[i].x - mean, d1 = v[i].y - mean, d2 = v[i].z - mean, d3 = v[i].w - mean;
                 q += (d0 * d0 + d1 * d1) + (d2 * d2 + d3 * d3);
             }
@@ -384,16 +446,16 @@ __global__ __launch_bounds__(64 * NW) void mlp_fused_kernel(MlpArgs a) {
             const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
             if (live) {
 #pragma unroll
-                for (int i = 0; i < NV; ++i) {
-                    const int c = CS * i + 4 * sub;
-                    const float4 g = *reinterpret_cast<const float4*>(a.ln_gamma[s] + c), b = *reinterpret_cast<const float4*>(a.ln_beta[s] + c);
+                for (int i = 0; i < ENV; ++i) {
+                    const int c = ECS * i + 4 * esub;
+                    const float4 g = eg[i], b = ebt[i];
                     const float n[4] = {(v[i].x - mean) * rstd * g.x + b.x, (v[i].y - mean) * rstd * g.y + b.y,
                                         (v[i].z - mean) * rstd * g.z + b.z, (v[i].w - mean) * rstd * g.w + b.w};
                     bf16x4 hi, lo;
 #pragma unroll
                     for (int j = 0; j < 4; ++j) { hi[j] = (bf16)n[j]; lo[j] = (bf16)(n[j] - (float)hi[j]); }
-                    *reinterpret_cast<bf16x4*>(a.ln_hi[s] + (int64_t)m * C + c) = hi;
-                    *reinterpret_cast<bf16x4*>(a.ln_lo[s] + (int64_t)m * C + c) = lo;
+                    *reinterpret_cast<bf16x4*>(a.ln_hi[s] + (int64_t)em * C + c) = hi;
+                    *reinterpret_cast<bf16x4*>(a.ln_lo[s] + (int64_t)em * C + c) = lo;
                 }
             }
         }
@@ -493,21 +555,21 @@ __global__ __launch_bounds__(256) void mlp_reduce_ln_kernel(MlpArgs a, int C, in
     }
 }
 
-template <int C, int NW>
+template <int C, int NW, int TOK = 64>
 int launch_c(const MlpArgs& a, int nstream, hipStream_t stream) {
-    // A image + H image (NW = 4) or A image with H laid over it + gamma / beta (NW = 8)
-    constexpr int lds = NW == 8 ? 64 * (C + 8) * 2 * 2 + 2 * C * 4 : (64 * (C + 8) + 64 * (32 * NW + 8)) * 2 * 2;
+    // A image + H image (NW = 4, 6) or A image with H laid over it + gamma / beta (NW = 8)
+    constexpr int lds = NW == 8 ? TOK * (C + 8) * 2 * 2 + 2 * C * 4 : (TOK * (C + 8) + TOK * (32 * NW + 8)) * 2 * 2;
     if (NW == 8 && a.nchunks != 1) return fail(SWF_ERR_UNSUPPORTED, "mlp_fused: the 8-wave kernel takes one hidden chunk per workgroup");
     static std::once_flag once;   // > 64 KB of dynamic LDS needs the attribute once per kernel (thread-safe)
     static hipError_t attr_err = hipSuccess;
     if (lds > 65536) {
         std::call_once(once, [] {
-            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+            attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&mlp_fused_kernel<C, NW, TOK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         });
         if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "mlp_fused: cannot raise the dynamic LDS limit to %d B", lds);
     }
-    dim3 grid((a.M + 63) / 64, a.splits, nstream);
-    hipLaunchKernelGGL((mlp_fused_kernel<C, NW>), grid, dim3(64 * NW), lds, stream, a);
+    dim3 grid((a.M + TOK - 1) / TOK, a.splits, nstream);
+    hipLaunchKernelGGL((mlp_fused_kernel<C, NW, TOK>), grid, dim3(64 * NW), lds, stream, a);
     SWF_TRY(check_launch("mlp_fused"));
     MlpArgs ra = a;   // the reduce kernels' residual is the row that entered LN2
     for (int s = 0; s < nstream; ++s)
@@ -534,6 +596,13 @@ static bool mlp_wide(int C, int HID) {
     return !off && C == 384 && HID % 256 == 0;
 }
 
+// C = 192 with a hidden width that is a multiple of 192: six waves on 192-wide hidden chunks, 32-token tiles, no hidden split
+// (SWF_MLP_TOK32=0 under SWF_DEBUG_SWITCHES: the 64-token kernel, tools only).  The rule looks at the layer shape only.
+static bool mlp_tok32(int C, int HID) {
+    static const bool off = [] { const char* e = debug_env("SWF_MLP_TOK32"); return e && e[0] == '0'; }();
+    return !off && C == 192 && HID % 192 == 0;
+}
+
 bool mlp_fused_supported(int C, int HID) {
     return (C == 128 || C == 192 || C == 256 || C == 384) && HID > 0 && HID % 128 == 0 && (int64_t)C * HID < (1 << 30);
 }
@@ -542,6 +611,7 @@ bool mlp_fused_supported(int C, int HID) {
 int mlp_fused_splits(int C, int HID) {
     static const int forced = [] { const char* e = debug_env("SWF_MLP_SPLITS"); return e ? atoi(e) : 0; }();   // tools: tuning override
     if (mlp_wide(C, HID)) return HID / 256;
+    if (mlp_tok32(C, HID)) return 1;
     if (forced > 0 && (HID / 128) % forced == 0) return forced;
     const int chunks = HID / 128;
     // measured at B=16 256x256 (us, kernel + reduce): C=192 hid 768: S=1 33, S=2 23+6, S=3 32+7; C=384 hid 1536: S=2 56, S=4 38+5,
@@ -569,8 +639,8 @@ int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream) {
     }
     a.M = d.M; a.HID = d.HID;
     a.splits = mlp_fused_splits(d.C, d.HID);
-    const bool wide = mlp_wide(d.C, d.HID);
-    a.nchunks = d.HID / (wide ? 256 : 128) / a.splits;
+    const bool wide = mlp_wide(d.C, d.HID), tok32 = mlp_tok32(d.C, d.HID);
+    a.nchunks = d.HID / (wide ? 256 : tok32 ? 192 : 128) / a.splits;
     a.scratch = d.scratch;
     if (d.ln_hi[0])
         for (int s = 0; s < nstream; ++s) {
@@ -581,7 +651,7 @@ int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream) {
         return fail(SWF_ERR_WORKSPACE, "mlp_fused: scratch too small for %d hidden splits", a.splits);
     switch (d.C) {
         case 128: return launch_c<128, 4>(a, nstream, stream);
-        case 192: return launch_c<192, 4>(a, nstream, stream);
+        case 192: return tok32 ? launch_c<192, 6, 32>(a, nstream, stream) : launch_c<192, 4>(a, nstream, stream);
         case 256: return launch_c<256, 4>(a, nstream, stream);
         case 384: return wide ? launch_c<384, 8>(a, nstream, stream) : launch_c<384, 4>(a, nstream, stream);
     }

@@ -20,9 +20,11 @@ def main():
     load_recipe_into(m, seed=17, flavor="stress")
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
     ir, vis = (torch.from_numpy(a) for a in synthetic_pair(2, 128, 128, seed_ir=21, seed_vis=22))
-    ref, u, pooled, med = G.fp64_uncertainty(O.model_forward, sd, cfg, ir, vis)
-    print("fp32 oracle vs fp64 oracle: median %.3e max %.3e" % (med, float(u.max())))
     m.to("cuda:0")
+    m.precision = "fp32"
+    exact = m(ir.cuda(), vis.cuda()).cpu()
+    ref, u, pooled, med = G.fp64_uncertainty(O.model_forward, sd, cfg, ir, vis, extra_fp32=(exact,))
+    print("fp32 (CPU oracle, GPU exact tier) vs fp64 oracle: median %.3e max %.3e" % (med, float(u.max())))
     for prec in ("fp32", "fast"):
         m.precision = prec
         out = m(ir.cuda(), vis.cuda()).cpu()

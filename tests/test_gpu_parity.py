@@ -314,12 +314,13 @@ def test_reference_checkpoint_to_gpu_forward(tmp_path):
     ir, vis = (torch.from_numpy(a) for a in synthetic_pair(2, 128, 128, seed_ir=21, seed_vis=22))
     # These stress weights (seed 17) put a patch of ill-conditioned pixels at (b=0, y 45..48, x 64..66): the reference's own fp32
     # answer differs from an fp64 evaluation by 5.5e-6 there, 44x its median (tests/diag_ckpt.py).  The max-error gate is the
-    # north star's 1e-3 of max|ref| plus C_ROUNDOFF x that measured fp32 uncertainty, and every pixel that needs the second term
+    # north star's 1e-3 of max|ref| plus C_ROUNDOFF x the measured fp32 uncertainty (CPU oracle and the GPU's exact tier, both against fp64), and every pixel that needs the second term
     # must be ill-conditioned by the fp64 measure (golden_util.close_conditioned); rel-L2 stays at 1e-3.
-    ref, u, pooled, med = G.fp64_uncertainty(O.model_forward, sd, cfg, ir, vis)
-    assert float(u.max()) >= G.K_ILL * med      # the conditioning story itself: the fp32 reference is that uncertain somewhere
     m.precision = "fp32"
-    _close(m(ir.to(DEV), vis.to(DEV)), ref, 5e-5, None)
+    exact = m(ir.to(DEV), vis.to(DEV)).cpu()
+    ref, u, pooled, med = G.fp64_uncertainty(O.model_forward, sd, cfg, ir, vis, extra_fp32=(exact,))
+    assert float(u.max()) >= G.K_ILL * med      # the conditioning story itself: the fp32 reference is that uncertain somewhere
+    _close(exact, ref, 5e-5, None)
     m.precision = "fast"
     l2, mx, n_ill = G.close_conditioned(m(ir.to(DEV), vis.to(DEV)), ref, pooled, med, TOL_FAST_L2, TOL_FAST_MAX)
     _PARITY_LOG.append((_CUR_TEST + "[fast, fp64-conditioned gate, %d pixels beyond 1e-3]" % n_ill, l2, mx))

@@ -69,7 +69,10 @@ int main() {
         {   // every workgroup's entry / exit, relative to the first entry (last launch)
             static unsigned long long wg[2 * 4096];
             CK(hipMemcpyFromSymbol(wg, HIP_SYMBOL(swf_mlp_wg), sizeof(wg)));
-            const int nwg = ((sh.M + 63) / 64) * S * 2;
+            const char* e32 = getenv("SWF_MLP_TOK32");
+            const bool t32 = sh.C == 192 && sh.HID % 192 == 0 && !(getenv("SWF_DEBUG_SWITCHES") && e32 && e32[0] == '0');   // as mlp_tok32() in kernels_mlp.hip
+            const int tok = t32 ? 32 : 64;
+            const int nwg = ((sh.M + tok - 1) / tok) * S * 2;
             std::vector<double> en, ex;
             unsigned long long t0 = ~0ull;
             for (int i = 0; i < nwg; ++i) t0 = std::min(t0, wg[2 * i]);
@@ -80,8 +83,12 @@ int main() {
         }
         const char* e8 = getenv("SWF_MLP8");
         const bool wide = sh.C == 384 && sh.HID % 256 == 0 && !(e8 && e8[0] == '0');   // as mlp_wide() in kernels_mlp.hip
-        const int nch = sh.HID / (wide ? 256 : 128) / S;
+        const char* e32b = getenv("SWF_MLP_TOK32");
+        const bool t32b = sh.C == 192 && sh.HID % 192 == 0 && !(getenv("SWF_DEBUG_SWITCHES") && e32b && e32b[0] == '0');
+        const int nch = sh.HID / (wide ? 256 : t32b ? 192 : 128) / S;
         printf("%s C=%d hid=%d S=%d chunks/WG=%d (us from kernel entry of WG %d): LN done %.2f", sh.name, sh.C, sh.HID, S, nch, SWF_MLP_PROBE, (h[1] - h[0]) * 0.01);
+        printf(" [prologue: rows+fold done %.2f | ring issued %.2f | gamma/beta in LDS %.2f | stats %.2f | barrier %.2f]", (h[50] - h[0]) * 0.01, (h[51] - h[0]) * 0.01,
+               (h[52] - h[0]) * 0.01, (h[53] - h[0]) * 0.01, (h[54] - h[0]) * 0.01);
         for (int c = 0; c < nch && c < 8; ++c)
             printf(" | ch%d fc1 %.2f H %.2f bar %.2f fc2 %.2f", c, (h[2 + 4 * c] - h[0]) * 0.01, (h[3 + 4 * c] - h[0]) * 0.01, (h[4 + 4 * c] - h[0]) * 0.01, (h[5 + 4 * c] - h[0]) * 0.01);
         printf(" | loop end %.2f | done %.2f\n", (h[40] - h[0]) * 0.01, (h[41] - h[0]) * 0.01);
