@@ -180,6 +180,15 @@ int swf_final_head_fwd(const swf_head_params* p, const float* x, const float* y,
                        int32_t B, int32_t H, int32_t W, int32_t ksize,
                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
 
+/* AutoPathMLP.forward (a003_AutoPathMLP.py:46-50) on NHWC tokens: out = fc2(ELU(fc1(in))) per stream, no norm, no residual
+ * (px / py: only fc1 and fc2 are read; py / y_* NULL for a single path).  SWF_PREC_FAST runs the level-0 width (24 channels,
+ * hidden 96 or 4) as ONE launch of the fused block kernel's MLP half, other shapes as split-bf16 GEMMs. */
+size_t swf_mlp_workspace_bytes(int32_t precision, int64_t tokens, int32_t channels, int32_t hidden);
+int swf_mlp_fwd(int32_t precision, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                const float* x_in, const float* y_in, float* x_out, float* y_out,
+                int64_t tokens, int32_t channels, int32_t hidden,
+                void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
 /* ---- token-level pieces used by the inner reference modules ------------------------------------ */
 /* out[tokens][n_out] = act(in[tokens][n_in] . W^T + b) (+ residual); act 0 = none, 1 = ELU(alpha=1).
  * nn.Linear (a001:42-61) and 1x1 nn.Conv2d on NHWC tokens (a003:21-22, a011:60-63).  Exact fp32. */

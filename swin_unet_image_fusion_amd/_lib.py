@@ -89,6 +89,8 @@ SIGNATURES = {
     "swf_patch_workspace_bytes": (_sz, [_i32] * 10),
     "swf_final_head_fwd": (C.c_int, [P(HeadParams), _vp, _vp, _vp, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_linear_fwd": (C.c_int, [P(Linear), _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp]),
+    "swf_mlp_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
+    "swf_mlp_fwd": (C.c_int, [_i32, P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _i64, _i32, _i32, _vp, _sz, _vp]),
     "swf_linear_workspace_bytes": (_sz, [_i32, _i64, _i32, _i32]),
     "swf_linear_fwd_prec": (C.c_int, [P(Linear), _i32, _vp, _vp, _vp, _i64, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_layernorm_fwd": (C.c_int, [P(Norm), _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -93,11 +93,21 @@ struct G24 {
 
 struct Win24Args {
     const float* in[2];
-    float* out[2];
+    float* out[2];       // half-block modes: a NULL out[s] drops that stream's stores (its waves only feed K / V to the other stream)
     const char* packed[2];
     const char* warm[2];
     int B, H, W, shift, cross, warm_bytes;
+    int ntok[2];         // MLP half (W24_MLP): token count of each stream's flat token list
 };
+
+// What one launch computes (template parameter MODE of window24_kernel):
+//   W24_BLOCK  the whole BasicBlock (a005:127-145)
+//   W24_ATTN   x + proj(attention(LN1 ...)) — AddAndLayerNormWithOtherModule around AutoPathWinAtt (a004:29-38, a002:58-82); with
+//              RAW: proj(attention(q, k, v)) on un-normalised inputs and no residual — WindowAttention.forward (a001:448-474),
+//              stream 0 = the query tensor and the output, stream 1 = the key / value tensor (its waves stop after K / V)
+//   W24_MLP    x + fc2(ELU(fc1(LN2 x))) — AddAndLayerNormWithOtherModule around AutoPathMLP (a004:29-38, a003:46-50); with RAW:
+//              fc2(ELU(fc1 x)) — AutoPathMLP.forward.  Tokens are a flat list (no windows): 64 per workgroup step and stream
+constexpr int W24_BLOCK = 0, W24_ATTN = 1, W24_MLP = 2;
 
 __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
     return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
@@ -211,6 +221,17 @@ __device__ __forceinline__ void layernorm_frags(const f32x16& res, const float* 
     split8(n + 8, xh[1], xl[1]);
 }
 
+// RAW modes: the un-normalised row as the operand fragments (slot 12 of lane half 0 = the constant 1 of the bias column)
+__device__ __forceinline__ void raw_frags(const f32x16& res, u32x4 (&xh)[2], u32x4 (&xl)[2]) {
+    float n[16];
+#pragma unroll
+    for (int i = 0; i < 12; ++i) n[i] = res[i];
+    n[12] = 1.0f;
+    n[13] = n[14] = n[15] = 0.f;
+    split8(n, xh[0], xl[0]);
+    split8(n + 8, xh[1], xl[1]);
+}
+
 // Attention of one wave: 32 queries x 64 keys x 8 heads.  ksrc / vsrc: the stream's K and V^T operand images in LDS (+ lane);
 // qf: the wave's own Q fragments; bias: relative-position bias of (stream, query block), C operand of the S^T MFMAs;
 // (with -inf where the shift mask applies).  Returns the O^T accumulator: registers 4a..4a+3 of
@@ -285,10 +306,13 @@ __device__ __forceinline__ f32x16 attention24(const u32x4* ksrc, const u32x4* vs
 // 15 padding tokens (row 7 / column 7) load zeros and store nothing (buffer addressing: an offset beyond the descriptor's
 // range reads 0 and drops the store), and as keys they carry -inf in the packed bias matrix, so their probabilities are 0.
 // The shift seam of the last window row / column sits at WS - WS/2 = 4 for both sizes: the structural masks are unchanged.
-template <int HID, int WS>
+template <int HID, int WS, int MODE = W24_BLOCK, bool RAW = false>
 __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args) {
     using G = G24<HID>;
     static_assert(WS == 7 || WS == 8, "window side");
+    static_assert(MODE == W24_BLOCK || MODE == W24_ATTN || MODE == W24_MLP, "mode");
+    static_assert(!RAW || MODE != W24_BLOCK, "RAW belongs to the half-block modes");
+    constexpr bool ATT = MODE != W24_MLP, MLP = MODE != W24_ATTN;
     __shared__ __attribute__((aligned(16))) char smem[G::l_total];
     u32x4* kimg = reinterpret_cast<u32x4*>(smem + G::l_k);   // [buf][stream][key tile][k-step][lane]
     u32x4* vimg = reinterpret_cast<u32x4*>(smem + G::l_v);   // [buf][stream][pv-step][lane]
@@ -296,9 +320,11 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ws = wave >> 1, qb = wave & 1, r = lane & 31, hf = lane >> 5;
-    const int H = args.H, W = args.W, nwx = W / WS, nwy = H / WS, npi = nwx * nwy;
-    const int nwin = args.B * npi;
+    const int H = args.H, W = args.W, nwx = MLP && !ATT ? 1 : W / WS, nwy = MLP && !ATT ? 1 : H / WS, npi = nwx * nwy;
+    // MLP half: a "window" is 64 consecutive tokens of the flat list; the streams may differ in length (single-stream callers split one list)
+    const int nwin = ATT ? args.B * npi : (max(args.ntok[0], args.ntok[1]) + 63) / 64;
     const int sh = args.shift ? WS / 2 : 0;
+    // (RAW attention: stream 1 is the key / value tensor of stream 0's queries; its waves stop after K / V and stream 0's skip K / V)
     const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
 
     for (int i = tid; i < 2 * 2 * 64; i += 256) lvec[i] = reinterpret_cast<const float*>(args.packed[i >> 7] + G::p_vec)[i & 127];
@@ -308,9 +334,10 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
     // the window loop and spilled 46 registers).  The token rows go the same way.
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
-    const int act_bytes = args.B * H * W * 24 * 4;   // < 2^31 (launch_win24)
+    const int act_bytes = ATT ? args.B * H * W * 24 * 4 : args.ntok[ws] * 24 * 4;   // < 2^31 (launch_win24)
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(args.in[ws])), 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, act_bytes, 0x00020000);
+    // a NULL output (half-block modes) becomes an empty descriptor: every store is out of range and dropped
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, (MODE == W24_BLOCK || args.out[ws]) ? act_bytes : 0, 0x00020000);
     const unsigned loff = (unsigned)lane * 16u;
     auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };   // own stream: Q, proj, MLP
     auto WK = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, loff, f * 1024, 0)); };   // K / V weights
@@ -330,7 +357,7 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
                 for (int e = 0; e < 4; ++e) bias[kt][q4 * 4 + e] = t[e];
             }
     };
-    load_bias();
+    if constexpr (ATT) load_bias();
     const bool half1 = hf != 0;
     const bool col_masked = half1 != (((r >> 2) & 1) != 0);   // last-window-column variant: this lane's keys lie across the seam
     __syncthreads();
@@ -351,7 +378,15 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
         oy = oy < oy - (unsigned)H ? oy : oy - (unsigned)H;
         ox = ox < ox - (unsigned)W ? ox : ox - (unsigned)W;
         // byte offset of the lane's first float4; padding tokens of a 7x7 window point beyond the buffer (reads 0, stores dropped)
-        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + (int)oy) * W + (int)ox) * 24 + 4 * (lane_w >> 5)) * 4) : 0x80000000u;
+        // (MLP half: flat token list, token 64 win + 32 qb + (lane & 31); past the stream's end -> out of range: reads 0, stores dropped)
+        const unsigned tokoff = [&]() -> unsigned {
+            if constexpr (ATT) {
+                return (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + (int)oy) * W + (int)ox) * 24 + 4 * (lane_w >> 5)) * 4) : 0x80000000u;
+            } else {
+                const int tok = 64 * win + 32 * qb + (lane_w & 31);
+                return tok < args.ntok[ws] ? (unsigned)((tok * 24 + 4 * (lane_w >> 5)) * 4) : 0x80000000u;
+            }
+        }();
         // rows 24..31 of every output tile have zero weights: registers 12..15 stay zero
         auto load_rows = [&](f32x16& dstv) {
 #pragma unroll
@@ -365,6 +400,8 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
         };
         const f32x16 zero16 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
+        f32x16 res;
+        if constexpr (ATT) {
         // ---- LN1, then Q (own stream's weights), K and V (weights of the stream that attends to these tokens) ----
         u32x4 qf[2];
         {
@@ -373,36 +410,43 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
             f32x16 x0;
             load_rows(x0);
             u32x4 xh[2], xl[2];
-            layernorm_frags(x0, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+            if constexpr (RAW) raw_frags(x0, xh, xl);
+            else layernorm_frags(x0, vec, G::V_LN1G, G::V_LN1B, xh, xl);
             f32x16 acc = zero16;
+            if (!(RAW && ws == 1)) {   // (wave-uniform) RAW: the key / value stream has no queries
 #pragma unroll
-            for (int s = 0; s < 2; ++s) acc = mma3(WF(G::F_QKV + 2 * s), WF(G::F_QKV + 2 * s + 1), xh[s], xl[s], acc);
-            float t[16];
+                for (int s = 0; s < 2; ++s) acc = mma3(WF(G::F_QKV + 2 * s), WF(G::F_QKV + 2 * s + 1), xh[s], xl[s], acc);
+                float t[16];
 #pragma unroll
-            for (int i = 0; i < 16; ++i) t[i] = acc[i];
-            qf[0] = pack8_f16(t);
-            qf[1] = pack8_f16(t + 8);
+                for (int i = 0; i < 16; ++i) t[i] = acc[i];
+                qf[0] = pack8_f16(t);
+                qf[1] = pack8_f16(t + 8);
+            }
             W24_FENCE();
-            acc = zero16;
+            if (!(RAW && ws == 0)) {   // RAW: the query stream's tokens are nobody's keys
+                float t[16];
+                acc = zero16;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) acc = mma3(WK(G::F_QKV + 4 + 2 * s), WK(G::F_QKV + 5 + 2 * s), xh[s], xl[s], acc);
+                for (int s = 0; s < 2; ++s) acc = mma3(WK(G::F_QKV + 4 + 2 * s), WK(G::F_QKV + 5 + 2 * s), xh[s], xl[s], acc);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) t[i] = acc[i];
-            u32x4* kdst = kimg + (((buf * 2 + kvs) * 2 + qb) * 2) * 64 + lane;
-            kdst[0] = pack8_f16(t);
-            kdst[64] = pack8_f16(t + 8);
-            W24_FENCE();
-            // V: tokens in rows (A = x fragments, B = weight fragments): register i of lane (channel r, hf) is token rho(i, hf)
-            acc = zero16;
+                for (int i = 0; i < 16; ++i) t[i] = acc[i];
+                u32x4* kdst = kimg + (((buf * 2 + kvs) * 2 + qb) * 2) * 64 + lane;
+                kdst[0] = pack8_f16(t);
+                kdst[64] = pack8_f16(t + 8);
+                W24_FENCE();
+                // V: tokens in rows (A = x fragments, B = weight fragments): register i of lane (channel r, hf) is token rho(i, hf)
+                acc = zero16;
 #pragma unroll
-            for (int s = 0; s < 2; ++s) acc = mma3<false>(xh[s], xl[s], WK(G::F_QKV + 8 + 2 * s), WK(G::F_QKV + 9 + 2 * s), acc);
+                for (int s = 0; s < 2; ++s) acc = mma3<false>(xh[s], xl[s], WK(G::F_QKV + 8 + 2 * s), WK(G::F_QKV + 9 + 2 * s), acc);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) t[i] = acc[i];
-            u32x4* vdst = vimg + ((buf * 2 + kvs) * 4 + 2 * qb) * 64 + lane;
-            vdst[0] = pack8_f16(t);
-            vdst[64] = pack8_f16(t + 8);
+                for (int i = 0; i < 16; ++i) t[i] = acc[i];
+                u32x4* vdst = vimg + ((buf * 2 + kvs) * 4 + 2 * qb) * 64 + lane;
+                vdst[0] = pack8_f16(t);
+                vdst[64] = pack8_f16(t + 8);
+            }
         }
         __syncthreads();   // K / V^T images of both streams complete (the buffers of the window before stay readable)
+        if (RAW && ws == 1) continue;   // (after the barrier of this window; the next window's images use the other buffer)
 
         // ---- attention of the wave's 32 queries, 8 heads ----
         // Shift mask (a001:217-315; the reference ASSIGNS -1e10 to the masked scores, so their probabilities are exactly 0):
@@ -428,9 +472,9 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
         }
 
         // ---- normalise, output projection + bias + residual: res is the C operand ----
-        f32x16 res;
         W24_FENCE();
-        load_rows(res);
+        if constexpr (RAW) res = zero16;
+        else load_rows(res);
         {
             float t[16];
 #pragma unroll
@@ -446,11 +490,15 @@ __global__ __launch_bounds__(256, W24_WAVES) void window24_kernel(Win24Args args
 #pragma unroll
             for (int s = 0; s < 2; ++s) res = mma3(WF(G::F_P + 2 * s), WF(G::F_P + 2 * s + 1), oh[s], ol[s], res);
         }
+        } else {   // MLP half: the rows as they are
+            load_rows(res);
+        }
 
         // ---- LN2, MLP: fc1 tile -> ELU -> split -> two k-steps of fc2 accumulating onto the residual ----
-        {
+        if constexpr (MLP) {
             u32x4 xh[2], xl[2];
-            layernorm_frags(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+            if constexpr (RAW) { raw_frags(res, xh, xl); res = zero16; }   // AutoPathMLP.forward: no norm, no residual
+            else layernorm_frags(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
 #pragma unroll
             for (int tI = 0; tI < G::NT1; ++tI) {
                 W24_FENCE();
@@ -803,8 +851,9 @@ __global__ __launch_bounds__(256) void pack24_kernel(Pack24Args a) {
     char* dst = a.dst[s];
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     const float qscale = kLog2e / sqrtf(3.0f);   // d^-0.5 (a001:32-34) and exp -> exp2
-    auto lin = [](const swf_linear& l, int n, int k, int ld) { return l.weight[n * ld + k]; };
-    auto bia = [](const swf_linear& l, int n) { return l.bias ? l.bias[n] : 0.f; };
+    // (the half-block entries pack only the half they run: a missing layer packs as zeros)
+    auto lin = [](const swf_linear& l, int n, int k, int ld) { return l.weight ? l.weight[n * ld + k] : 0.f; };
+    auto bia = [](const swf_linear& l, int n) { return (l.weight && l.bias) ? l.bias[n] : 0.f; };
 
     for (int idx = gtid; idx < G::NFRAG * 512; idx += gsz) {
         const int f = idx >> 9, lane = (idx >> 3) & 63, e = idx & 7;
@@ -855,15 +904,16 @@ __global__ __launch_bounds__(256) void pack24_kernel(Pack24Args a) {
         const int hf = i >> 6, j = i & 63, which = j / 12, k = j % 12;
         const int c = 8 * (k >> 2) + 4 * hf + (k & 3);
         float v = 0.f;
-        if (which == 0) v = p.ln1.gamma[c];
-        else if (which == 1) v = p.ln1.beta[c];
-        else if (which == 2) v = p.ln2.gamma[c];
-        else if (which == 3) v = p.ln2.beta[c];
-        else if (which == 4) v = p.fc2.bias ? p.fc2.bias[c] : 0.f;
+        if (which == 0) v = p.ln1.gamma ? p.ln1.gamma[c] : 1.f;
+        else if (which == 1) v = p.ln1.beta ? p.ln1.beta[c] : 0.f;
+        else if (which == 2) v = p.ln2.gamma ? p.ln2.gamma[c] : 1.f;
+        else if (which == 3) v = p.ln2.beta ? p.ln2.beta[c] : 0.f;
+        else if (which == 4) v = (p.fc2.weight && p.fc2.bias) ? p.fc2.bias[c] : 0.f;
         vec[i] = v;
     }
     // relative-position bias (a001:113-144), exp2 units, the S^T accumulator registers of each lane: [query block][lane][key tile][register]
     float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    if (!p.attn.bias_table) return;   // MLP half: no attention, the bias section is never read
     if (a.ws == 16) {
         // 16x16 windows: one S^T tile per distance d = kt - qb + 7 between the key tile and the query tile (a tile = two window
         // rows): [d][lane][reg], key = rho(reg, lane half), query = lane & 31, row = index >> 4, column = index & 15
@@ -918,6 +968,46 @@ int pack_win24(const swf_block_desc& d, const swf_block_stream_params& px, const
     if (d.hidden == 96) hipLaunchKernelGGL((pack24_kernel<96>), dim3(32, 2), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((pack24_kernel<4>), dim3(32, 2), dim3(256), 0, stream, a);
     return check_launch("pack_win24");
+}
+
+size_t win24_half_packed_bytes(int channels, int hidden) {
+    if (channels != 24 || (hidden != 96 && hidden != 4)) return 0;
+    return align_up(hidden == 96 ? G24<96>::p_total : G24<4>::p_total, 256);
+}
+
+// Half-block launches (8x8 / 7x7 windows).  mode W24_ATTN: x_out = x + proj(attention(LN1 ...)) for both streams (raw = 0), or
+// out = proj(attention(q, kv, kv)) with q = x_in, kv = y_in, y_out = NULL (raw = 1; packed_y = packed_x).  mode W24_MLP: tokens as
+// flat lists of ntok_x / ntok_y rows (H, W ignored).  A NULL output drops that stream's stores.
+int launch_win24_half(const swf_block_desc& d, int mode, int raw, const void* packed_x, const void* packed_y, const float* x_in,
+                      const float* y_in, float* x_out, float* y_out, int B, int H, int W, int ntok_x, int ntok_y, hipStream_t stream) {
+    const int wsd = d.attn.win_h;
+    if (mode != W24_ATTN && mode != W24_MLP) return fail(SWF_ERR_UNSUPPORTED, "win24_half: mode %d", mode);
+    if (d.attn.channels != 24 || (d.hidden != 96 && d.hidden != 4)) return fail(SWF_ERR_UNSUPPORTED, "win24_half: shape not covered");
+    Win24Args a{};
+    a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
+    a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
+    a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross; a.ntok[0] = ntok_x; a.ntok[1] = ntok_y;
+    int nwin;
+    if (mode == W24_ATTN) {
+        if (!win24_supported(d) || wsd == 16 || H % wsd || W % wsd) return fail(SWF_ERR_UNSUPPORTED, "win24_half: shape not covered");
+        if ((int64_t)B * H * W * 24 * 4 >= (int64_t(1) << 31)) return fail(SWF_ERR_UNSUPPORTED, "win24_half: map exceeds the 2 GB buffer window");
+        nwin = B * (H / wsd) * (W / wsd);
+    } else {
+        if ((int64_t)std::max(ntok_x, ntok_y) * 24 * 4 >= (int64_t(1) << 31) || ntok_x <= 0) return fail(SWF_ERR_UNSUPPORTED, "win24_half: token count");
+        nwin = (std::max(ntok_x, ntok_y) + 63) / 64;
+    }
+    const dim3 grid(std::min(nwin, W24_WAVES * num_cus24())), blk(256);
+#define W24_LAUNCH(HID_, WS_, MODE_, RAW_) hipLaunchKernelGGL((window24_kernel<HID_, WS_, MODE_, RAW_>), grid, blk, 0, stream, a)
+    if (mode == W24_ATTN) {   // the MLP geometry is irrelevant: the hidden-96 image layout serves
+        if (wsd == 8) { if (raw) W24_LAUNCH(96, 8, W24_ATTN, true); else W24_LAUNCH(96, 8, W24_ATTN, false); }
+        else { if (raw) W24_LAUNCH(96, 7, W24_ATTN, true); else W24_LAUNCH(96, 7, W24_ATTN, false); }
+    } else if (d.hidden == 96) {
+        if (raw) W24_LAUNCH(96, 8, W24_MLP, true); else W24_LAUNCH(96, 8, W24_MLP, false);
+    } else {
+        if (raw) W24_LAUNCH(4, 8, W24_MLP, true); else W24_LAUNCH(4, 8, W24_MLP, false);
+    }
+#undef W24_LAUNCH
+    return check_launch("window24 (half block)");
 }
 
 int launch_win24(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,

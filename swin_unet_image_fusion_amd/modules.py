@@ -265,29 +265,30 @@ class AutoPathMLP(_FwdAlias, nn.Module):
             setattr(self, f"dropout_{s}_2", d2)
             setattr(self, f"sequence_{s}", nn.Sequential(c1, activation_func, d1, c2, d2))
 
-    def _one(self, t: Tensor, s: str) -> Tensor:
+    def _params(self, s: str) -> L.BlockStreamParams:
+        p = L.BlockStreamParams()
+        p.fc1, p.fc2 = _lin(getattr(self, f"mlp_{s}_1")), _lin(getattr(self, f"mlp_{s}_2"))
+        return p
+
+    def forward(self, x, y):
+        """a003:46-50 through swf_mlp_fwd: both streams in one call (one launch of the fused kernel's MLP half at level-0 width)."""
+        _check_forward_only(self, x, y)
         _require_elu(self.activation_func)
         if self.training and self.drop_ratio:
             raise NotImplementedError("dropout > 0 in training mode is outside the forward-only HIP path")
-        b, c, h, w = t.shape
-        tn = _to_nhwc(t)
-        lib = L.lib()
-        hid = torch.empty((b, h, w, self.hidden_dims), dtype=torch.float32, device=t.device)
-        out = torch.empty((b, h, w, c), dtype=torch.float32, device=t.device)
-        l1, l2 = _lin(getattr(self, f"mlp_{s}_1")), _lin(getattr(self, f"mlp_{s}_2"))
-        n = b * h * w
-        prec = _precision_code(self.precision)
-        ws, wsn = _workspace(max(lib.swf_linear_workspace_bytes(prec, n, c, self.hidden_dims),
-                                 lib.swf_linear_workspace_bytes(prec, n, self.hidden_dims, c)), t.device)
-        L.check(lib.swf_linear_fwd_prec(C.byref(l1), prec, _ptr(tn), None, _ptr(hid), n, c, self.hidden_dims, 1, ws, wsn, _stream(t.device)))
-        L.check(lib.swf_linear_fwd_prec(C.byref(l2), prec, _ptr(hid), None, _ptr(out), n, self.hidden_dims, c, 0, ws, wsn, _stream(t.device)))
-        return _to_nchw(out)
-
-    def forward(self, x, y):
-        _check_forward_only(self, x, y)
-        if self.use_dual_path or y is not None:
-            return self._one(x, "x"), self._one(y, "y")
-        return self._one(x, "x")
+        dual = self.use_dual_path or y is not None
+        b, c, h, w = x.shape
+        xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
+        ox = torch.empty_like(xn)
+        oy = torch.empty_like(yn) if dual else None
+        lib, prec, n = L.lib(), _precision_code(self.precision), b * h * w
+        px, py = self._params("x"), (self._params("y") if dual else None)
+        ws, wsn = _workspace(lib.swf_mlp_workspace_bytes(prec, n, c, self.hidden_dims), x.device)
+        L.check(lib.swf_mlp_fwd(prec, C.byref(px), C.byref(py) if dual else None, _ptr(xn), _ptr(yn) if dual else None, _ptr(ox),
+                                _ptr(oy) if dual else None, n, c, self.hidden_dims, ws, wsn, _stream(x.device)))
+        if dual:
+            return _to_nchw(ox), _to_nchw(oy)
+        return _to_nchw(ox)
 
 
 # ----------------------------------------------------------------------------------------------

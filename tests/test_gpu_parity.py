@@ -170,6 +170,53 @@ def test_inner_modules_compose_like_the_block(precision):
     _close_(mx, rx); _close_(my, ry)
 
 
+_HALVES = [  # level-0 width through the fused half-block kernels (window24_kernel<.., W24_ATTN / W24_MLP>): win, hidden, dual, cross, shift, (B,H,W)
+    (8, 96, True, True, True, (2, 16, 24)),
+    (8, 96, True, False, False, (1, 24, 8)),
+    (8, 96, False, False, True, (1, 8, 16)),      # single-path block: one stream through the two-stream kernel
+    (7, 96, True, True, True, (1, 14, 21)),
+    (8, 4, True, True, False, (3, 8, 8)),         # decoder width: hidden 4
+]
+
+
+@pytest.mark.parametrize("case", _HALVES, ids=[f"w{c[0]}_hid{c[1]}_dual{int(c[2])}_c{int(c[3])}s{int(c[4])}" for c in _HALVES])
+def test_standalone_halves_level0_fast_vs_oracle(case):
+    """a004 around a002 / a003 and the bare a002 / a003 / a001 modules at C = 24 in the fast tier: each is ONE launch of the level-0
+    block kernel with the other half compiled out; compared with the oracle's functions of the same names."""
+    win, hid, dual, cross, shift, (b, h, w) = case
+    m = BasicBlock(24, 8, 3, (win, win), shift, dual, cross, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
+    load_recipe_into(m, seed=31, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, y = G.randn((b, 24, h, w), 701), G.randn((b, 24, h, w), 702)
+    m.to(DEV)
+    for sub in m.modules():
+        if hasattr(sub, "precision"):
+            sub.precision = "fast"
+    xd, yd = x.to(DEV), (y.to(DEV) if dual else None)
+    kw = dict(num_heads=8, dims_per_head=3, window_size=(win, win), use_cyclic_shift=shift)
+    chk = lambda got, ref: _close(got, ref, TOL_FAST_L2, TOL_FAST_MAX)
+    if dual:
+        rx, ry = O.auto_path_win_att(sd, "auto_path_win_att.", x, y, cross=cross, **kw)
+        ax, ay = m.auto_path_win_att(xd, yd)
+        chk(ax, rx); chk(ay, ry)
+        rx, ry = O.auto_path_mlp(sd, "auto_path_mlp.", x, y)
+        ax, ay = m.auto_path_mlp(xd, yd)
+        chk(ax, rx); chk(ay, ry)
+        # the two pre-norm residual halves compose to the block (a005:138-141)
+        bx, by = O.basic_block(sd, "", x, y, cross=cross, shift=shift, num_heads=8, dims_per_head=3, window_size=(win, win))
+        x1, y1 = m.stage_1(xd, yd)
+        x2, y2 = m.stage_2(x1, y1)
+        chk(x2, bx); chk(y2, by)
+    else:
+        wa = m.auto_path_win_att.window_attention_x
+        chk(wa(xd, xd, xd), O.window_attention(sd, "auto_path_win_att.window_attention_x.", x, x, x, **kw))
+        x1 = m.stage_1(xd, None)
+        x2 = m.stage_2(x1, None)
+        full = m(xd)
+        full = full[0] if isinstance(full, tuple) else full
+        chk(x2, full.cpu())      # the fused single-path block (generic fast tier) and the two fused halves agree within the tier's bar
+
+
 @pytest.mark.parametrize("name", G.cases("patch_layer"))
 def test_patch_layer(name):
     meta, arr = G.load(name)
