@@ -57,11 +57,26 @@ struct G48 {
 
 struct Win48Args {
     const float* in[2];
-    float* out[2];
+    float* out[2];       // half-block modes: a NULL out[s] drops that stream's stores
     const char* packed[2];
     const char* warm[2];
     int B, H, W, shift, cross, warm_bytes;
+    int ntok[2];         // MLP half (W48_MLP): token count of each stream's flat token list
 };
+
+// launch modes of window48_kernel: the whole block, or one half of it as a launch of its own (kernels_win24.hip: W24_*; RAW = no
+// LayerNorm, no residual; RAW attention: stream 0 = queries and output, stream 1 = key / value tensor)
+constexpr int W48_BLOCK = 0, W48_ATTN = 1, W48_MLP = 2;
+
+// RAW modes: the un-normalised row as the operand fragments of the next linear layer
+__device__ __forceinline__ void raw48(const f32x16& x0, const f32x16& x1, u32x4 (&xh)[3], u32x4 (&xl)[3]) {
+    float n[24];
+#pragma unroll
+    for (int i = 0; i < 24; ++i) n[i] = i < 16 ? x0[i] : x1[i - 16];
+    split8(n, xh[0], xl[0]);
+    split8(n + 8, xh[1], xl[1]);
+    split8(n + 16, xh[2], xl[2]);
+}
 
 // LayerNorm (eps 1e-5, biased variance) of the lane's token: 24 of its 48 channels sit in this lane (tile 0 registers 0..15,
 // tile 1 registers 0..7), the other 24 in lane l ^ 32.  Output: the three k-step fragments of the next linear layer.
@@ -157,10 +172,12 @@ __device__ __forceinline__ void attention48(const u32x4* ksrc, const u32x4* vsrc
 // WS = window side, 8 or 7 (the reference's default, A000_CONFIG.py:55).  A 7x7 window runs on the same 8x8 token grid, as in
 // kernels_win24.hip: the 15 padding tokens load zeros and store nothing (an offset beyond the buffer descriptor's range) and
 // carry -inf in the packed bias matrix as keys; the shift seam sits at WS - WS/2 = 4 for both sizes.
-template <int HID, int WS>
+template <int HID, int WS, int MODE = W48_BLOCK, bool RAW = false>
 __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args) {
     using G = G48<HID>;
     static_assert(WS == 7 || WS == 8, "window side");
+    static_assert(!RAW || MODE != W48_BLOCK, "RAW belongs to the half-block modes");
+    constexpr bool ATT = MODE != W48_MLP, MLP = MODE != W48_ATTN;
     __shared__ __attribute__((aligned(16))) char smem[G::l_total];
     u32x4* kimg = reinterpret_cast<u32x4*>(smem + G::l_k);   // [stream][key tile][vch tile][k-step][lane]
     u32x4* vimg = reinterpret_cast<u32x4*>(smem + G::l_v);   // [stream][vch tile][pv-step][lane]
@@ -168,16 +185,16 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ws = wave >> 1, qb = wave & 1, r = lane & 31, hf = lane >> 5;
-    const int H = args.H, W = args.W, nwx = W / WS, nwy = H / WS, npi = nwx * nwy;
-    const int nwin = args.B * npi;
+    const int H = args.H, W = args.W, nwx = ATT ? W / WS : 1, nwy = ATT ? H / WS : 1, npi = nwx * nwy;
+    const int nwin = ATT ? args.B * npi : (max(args.ntok[0], args.ntok[1]) + 63) / 64;   // MLP half: 64 tokens of the flat list per step
     const int sh = args.shift ? WS / 2 : 0;
     const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
 
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
-    const int act_bytes = args.B * H * W * 48 * 4;   // < 2^31 (launch_win48)
+    const int act_bytes = ATT ? args.B * H * W * 48 * 4 : args.ntok[ws] * 48 * 4;   // < 2^31 (launch_win48)
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(args.in[ws])), 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, (MODE == W48_BLOCK || args.out[ws]) ? act_bytes : 0, 0x00020000);
     const unsigned loff = (unsigned)lane * 16u;
     auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };   // own stream: Q, proj, MLP
     auto WK = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, loff, f * 1024, 0)); };   // K / V weights
@@ -197,7 +214,14 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
         oy = oy >= H ? oy - H : oy;
         ox = ox >= W ? ox - W : ox;
         // byte offset of the lane's first float4; padding tokens of a 7x7 window point beyond the buffer (reads 0, stores dropped)
-        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 48 + 4 * hf) * 4) : 0x80000000u;
+        const unsigned tokoff = [&]() -> unsigned {
+            if constexpr (ATT) {
+                return (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 48 + 4 * hf) * 4) : 0x80000000u;
+            } else {   // flat token list; past the stream's end: out of range (reads 0, stores dropped)
+                const int tok = 64 * win + 32 * qb + r;
+                return tok < args.ntok[ws] ? (unsigned)((tok * 48 + 4 * hf) * 4) : 0x80000000u;
+            }
+        }();
         // the lane's 24 channels: tile 0 registers 4a.. = channels 8a+4hf.. (a < 4), tile 1 registers 4a.. = channels 32+8a+4hf.. (a < 2)
         auto load_rows = [&](f32x16& t0, f32x16& t1) {
 #pragma unroll
@@ -210,6 +234,8 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
             for (int i = 8; i < 16; ++i) t1[i] = 0.f;   // rows 48..63 of every output tile have zero weights: stay zero
         };
 
+        f32x16 res0, res1;
+        if constexpr (ATT) {
         // ---- LN1, then Q (own stream's weights), K and V (weights of the stream that attends to these tokens) ----
         u32x4 qf[2][2];
         {
@@ -234,7 +260,8 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
                 __syncthreads();
             }
             u32x4 xh[3], xl[3];
-            layernorm48(x0, x1, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+            if constexpr (RAW) raw48(x0, x1, xh, xl);
+            else layernorm48(x0, x1, vec, G::V_LN1G, G::V_LN1B, xh, xl);
             float t[16];
 #pragma unroll
             for (int ph = 0; ph < 6; ++ph) {
@@ -244,7 +271,11 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
                 SWF_WF_FENCE();
                 const u32x4 (&w)[6] = wq[ph & 1];
                 f32x16 acc = zero16;
-                if (m < 2) {
+                if (RAW && (m == 0 ? ws == 1 : ws == 0)) {
+                    // (wave-uniform) RAW attention: the key / value stream has no queries, the query stream's tokens are nobody's keys;
+                    // the barrier of the first K phase is every wave's
+                    if (ph == 2 && win != (int)blockIdx.x) __syncthreads();
+                } else if (m < 2) {
 #pragma unroll
                     for (int s = 0; s < 3; ++s) acc = mma3(w[2 * s], w[2 * s + 1], xh[s], xl[s], acc);   // [virtual channel][token]
                     const float* bsrc = m == 0 ? vec + G::V_BQ : veck + G::V_BK;
@@ -284,6 +315,7 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
                 bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
             }
         __syncthreads();   // K / V^T images of both streams complete
+        if (RAW && ws == 1) continue;   // RAW: the key / value stream is done with this window
 
         // ---- attention of the wave's 32 queries, 8 heads (shift mask: kernels_win24.hip) ----
         f32x16 o[2];
@@ -301,10 +333,10 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
         }
 
         // ---- normalise (denominator: lane half 1, register 4q+2), output projection + bias + residual ----
-        f32x16 res0, res1;
         u32x4 wpj[16];   // all 16 projection fragments ([out tile 2][k-step 4][hi, lo]): requested here, in flight under the normalisation
         SWF_WF_FENCE();
-        load_rows(res0, res1);
+        if constexpr (RAW) { res0 = zero16; res1 = zero16; }
+        else load_rows(res0, res1);
 #pragma unroll
         for (int i = 0; i < 16; ++i) wpj[i] = WF(G::F_P + i);
         SWF_WF_FENCE();
@@ -331,8 +363,16 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
             }
         }
 
+        } else {   // MLP half: the rows as they are; the fp32 vectors once per launch
+            load_rows(res0, res1);
+            if (win == (int)blockIdx.x) {
+                fill_vectors<G::VSTREAM / 4, 256>(lvec, args.packed[0] + G::p_vec, args.packed[1] + G::p_vec, tid);
+                __syncthreads();
+            }
+        }
+
         // ---- LN2, MLP: fc1 tile -> ELU -> split -> two k-steps of fc2 accumulating onto the residual ----
-        {
+        if constexpr (MLP) {
             // fc1 fragments of tile tI+1 and the fc2 fragments of tile tI are requested at the top of tile tI (see the Q/K/V phases)
             u32x4 w1[2][6];
             auto req1 = [&](int tI, u32x4 (&dst)[6]) {
@@ -355,7 +395,8 @@ __global__ __launch_bounds__(256, W48_WAVES) void window48_kernel(Win48Args args
             req1(0, w1[0]);
             req2(0, w2[0]);
             u32x4 xh[3], xl[3];
-            layernorm48(res0, res1, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+            if constexpr (RAW) { raw48(res0, res1, xh, xl); res0 = zero16; res1 = zero16; }   // AutoPathMLP.forward: no norm, no residual
+            else layernorm48(res0, res1, vec, G::V_LN2G, G::V_LN2B, xh, xl);
 #pragma unroll
             for (int tI = 0; tI < G::NT1; ++tI) {
                 SWF_WF_FENCE();
@@ -741,7 +782,9 @@ __global__ __launch_bounds__(256) void pack48_kernel(Pack48Args a) {
     char* dst = a.dst[st];
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     const float qscale = kLog2e / sqrtf(6.0f);   // d^-0.5 (a001:32-34) and exp -> exp2
-    auto bia = [](const swf_linear& l, int n) { return l.bias ? l.bias[n] : 0.f; };
+    // (the half-block entries pack only the half they run: a missing layer packs as zeros, a missing norm as identity)
+    auto bia = [](const swf_linear& l, int n) { return (l.weight && l.bias) ? l.bias[n] : 0.f; };
+    auto wgt = [](const swf_linear& l, int i) { return l.weight ? l.weight[i] : 0.f; };
 
     for (int idx = gtid; idx < G::NFRAG * 512; idx += gsz) {
         const int f = idx >> 9, lane = (idx >> 3) & 63, e = idx & 7, r = lane & 31, hf = lane >> 5;
@@ -753,24 +796,24 @@ __global__ __launch_bounds__(256) void pack48_kernel(Pack48Args a) {
             const int k = kslot(s, hf, e), head = 4 * T + (r >> 3), c = r & 7;
             const swf_linear& l = m == 0 ? p.attn.q : m == 1 ? p.attn.k : p.attn.v;
             if (c < 6 && k < 48) {
-                val = l.weight[(head * 6 + c) * 48 + k];
+                val = wgt(l, (head * 6 + c) * 48 + k);
                 if (m == 0) val *= qscale;
             }
         } else if (f < G::F_W1) {   // projection: row = output channel 32To + r; k = virtual channel of O, head 0's row 6 (= 1) carries the bias
             const int g = (f - G::F_P) >> 1, ks = g & 3, To = g >> 2;
             hl = f & 1;
             const int n = 32 * To + r, v = kslot(ks, hf, e), head = v >> 3, c = v & 7;
-            if (n < 48) val = c < 6 ? p.attn.proj.weight[n * 48 + head * 6 + c] : (v == 6 ? bia(p.attn.proj, n) : 0.f);
+            if (n < 48) val = c < 6 ? wgt(p.attn.proj, n * 48 + head * 6 + c) : (v == 6 ? bia(p.attn.proj, n) : 0.f);
         } else if (f < G::F_W2) {   // fc1 (exp2 units): row = hidden unit
             const int g = (f - G::F_W1) >> 1, s = g % 3, tI = g / 3;
             hl = f & 1;
             const int k = kslot(s, hf, e), hid = 32 * tI + r;
-            if (k < 48) val = p.fc1.weight[hid * 48 + k] * kLog2e;
+            if (k < 48) val = wgt(p.fc1, hid * 48 + k) * kLog2e;
         } else {   // fc2 (x ln 2): row = output channel; k = hidden unit in accumulator order
             const int g = (f - G::F_W2) >> 1, u = g % G::KU, To = g / G::KU;
             hl = f & 1;
             const int n = 32 * To + r, hid = kslot(u, hf, e);
-            if (n < 48) val = p.fc2.weight[n * HID + hid] * kLn2;
+            if (n < 48) val = wgt(p.fc2, n * HID + hid) * kLn2;
         }
         const bf16 hi = (bf16)val;
         reinterpret_cast<bf16*>(dst)[idx] = hl ? (bf16)(val - (float)hi) : hi;
@@ -783,7 +826,8 @@ __global__ __launch_bounds__(256) void pack48_kernel(Pack48Args a) {
             if (j < G::V_BQ) {   // 24-channel vectors: entry k = register index (tile 0: 0..15, tile 1: 16..23)
                 const int which = j / 24, k = j % 24;
                 const int c = k < 16 ? rho(k, hf) : 32 + rho(k - 16, hf);
-                v = which == 0 ? p.ln1.gamma[c] : which == 1 ? p.ln1.beta[c] : which == 2 ? p.ln2.gamma[c] : which == 3 ? p.ln2.beta[c] : bia(p.fc2, c);
+                v = which == 0 ? (p.ln1.gamma ? p.ln1.gamma[c] : 1.f) : which == 1 ? (p.ln1.beta ? p.ln1.beta[c] : 0.f)
+                  : which == 2 ? (p.ln2.gamma ? p.ln2.gamma[c] : 1.f) : which == 3 ? (p.ln2.beta ? p.ln2.beta[c] : 0.f) : bia(p.fc2, c);
             } else if (j < G::V_B1) {   // Q / K bias in accumulator order; K's spare row 7 is the constant 1
                 const int isk = j >= G::V_BK, k = (j - (isk ? G::V_BK : G::V_BQ)), T = k >> 4, vch = 32 * T + rho(k & 15, hf);
                 const int head = vch >> 3, c = vch & 7;
@@ -801,6 +845,7 @@ __global__ __launch_bounds__(256) void pack48_kernel(Pack48Args a) {
     }
     // relative-position bias (a001:113-144), exp2 units: [query block][key tile][register / 4][lane][register % 4]
     float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    if (!p.attn.bias_table) return;   // MLP half: the bias section is never read
     if (a.ws == 16) {   // [distance kt - qb + 7][register / 4][lane][register % 4]; a tile = two window rows of 16
         for (int i = gtid; i < 15 * 16 * 64; i += gsz) {
             const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, d = i >> 10;
@@ -853,6 +898,44 @@ int pack_win48(const swf_block_desc& d, const swf_block_stream_params& px, const
     if (d.hidden == 192) hipLaunchKernelGGL((pack48_kernel<192>), dim3(64, 2), dim3(256), 0, stream, a);
     else hipLaunchKernelGGL((pack48_kernel<96>), dim3(64, 2), dim3(256), 0, stream, a);
     return check_launch("pack_win48");
+}
+
+size_t win48_half_packed_bytes(int channels, int hidden) {
+    if (channels != 48 || (hidden != 192 && hidden != 96)) return 0;
+    return align_up(hidden == 192 ? G48<192>::p_total : G48<96>::p_total, 256);
+}
+
+// Half-block launches (8x8 / 7x7 windows): see launch_win24_half (kernels_win24.hip) for the contract.
+int launch_win48_half(const swf_block_desc& d, int mode, int raw, const void* packed_x, const void* packed_y, const float* x_in,
+                      const float* y_in, float* x_out, float* y_out, int B, int H, int W, int ntok_x, int ntok_y, hipStream_t stream) {
+    const int wsd = d.attn.win_h;
+    if (mode != W48_ATTN && mode != W48_MLP) return fail(SWF_ERR_UNSUPPORTED, "win48_half: mode %d", mode);
+    if (d.attn.channels != 48 || (d.hidden != 192 && d.hidden != 96)) return fail(SWF_ERR_UNSUPPORTED, "win48_half: shape not covered");
+    Win48Args a{};
+    a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
+    a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
+    a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross; a.ntok[0] = ntok_x; a.ntok[1] = ntok_y;
+    int nwin;
+    if (mode == W48_ATTN) {
+        if (!win48_supported(d) || wsd == 16 || H % wsd || W % wsd) return fail(SWF_ERR_UNSUPPORTED, "win48_half: shape not covered");
+        if ((int64_t)B * H * W * 48 * 4 >= (int64_t(1) << 31)) return fail(SWF_ERR_UNSUPPORTED, "win48_half: map exceeds the 2 GB buffer window");
+        nwin = B * (H / wsd) * (W / wsd);
+    } else {
+        if ((int64_t)std::max(ntok_x, ntok_y) * 48 * 4 >= (int64_t(1) << 31) || ntok_x <= 0) return fail(SWF_ERR_UNSUPPORTED, "win48_half: token count");
+        nwin = (std::max(ntok_x, ntok_y) + 63) / 64;
+    }
+    const dim3 grid(std::min(nwin, W48_WAVES * num_cus48())), blk(256);
+#define W48_LAUNCH(HID_, WS_, MODE_, RAW_) hipLaunchKernelGGL((window48_kernel<HID_, WS_, MODE_, RAW_>), grid, blk, 0, stream, a)
+    if (mode == W48_ATTN) {   // the MLP geometry is irrelevant: the hidden-192 image layout serves
+        if (wsd == 8) { if (raw) W48_LAUNCH(192, 8, W48_ATTN, true); else W48_LAUNCH(192, 8, W48_ATTN, false); }
+        else { if (raw) W48_LAUNCH(192, 7, W48_ATTN, true); else W48_LAUNCH(192, 7, W48_ATTN, false); }
+    } else if (d.hidden == 192) {
+        if (raw) W48_LAUNCH(192, 8, W48_MLP, true); else W48_LAUNCH(192, 8, W48_MLP, false);
+    } else {
+        if (raw) W48_LAUNCH(96, 8, W48_MLP, true); else W48_LAUNCH(96, 8, W48_MLP, false);
+    }
+#undef W48_LAUNCH
+    return check_launch("window48 (half block)");
 }
 
 int launch_win48(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,

@@ -11,6 +11,7 @@
 #include <cstdlib>
 #include "kernels_window.h"
 #include "kernels_win24.h"
+#include "kernels_win48.h"
 #include "kernels_deep.h"
 #include "kernels_patch.h"
 #include "kernels_patchrr.h"
@@ -977,34 +978,45 @@ const char* swf_status_string(int status) {
 }
 
 // ---- fast tier of the stand-alone module entries at level-0 width (C = 24): the block kernel with the other half compiled out ----
-static bool half24_attn_shape(const swf_attn_desc& a, int H, int W) {
-    return a.channels == 24 && a.heads == 8 && a.head_dim == 3 && a.win_h == a.win_w && (a.win_h == 8 || a.win_h == 7) &&
-           H % a.win_h == 0 && W % a.win_w == 0;
+// (levels 0 and 1: C = 24 / 48, 8 heads of C / 8, 8x8 or 7x7 windows; hidden widths of the encoder / decoder blocks)
+static bool half_attn_shape(const swf_attn_desc& a, int H, int W) {
+    return (a.channels == 24 || a.channels == 48) && a.heads == 8 && a.head_dim * 8 == a.channels && a.win_h == a.win_w &&
+           (a.win_h == 8 || a.win_h == 7) && H % a.win_h == 0 && W % a.win_w == 0;
+}
+static int half_attn_hidden(int C) { return C == 24 ? 96 : 192; }   // the attention half runs on the wide-MLP image layout (fc sections unused)
+static size_t half_packed_bytes(int C, int hid) { return C == 24 ? win24_half_packed_bytes(C, hid) : C == 48 ? win48_half_packed_bytes(C, hid) : 0; }
+static int half_pack(const swf_block_desc& bd, const swf_block_stream_params& sx, const swf_block_stream_params& sy, char* pk, size_t pb, hipStream_t st) {
+    return bd.attn.channels == 24 ? pack_win24(bd, sx, sy, pk, pk + pb, st) : pack_win48(bd, sx, sy, pk, pk + pb, st);
+}
+static int half_launch(const swf_block_desc& bd, int mode, int raw, const char* pk, size_t pb, const float* x_in, const float* y_in, float* x_out,
+                       float* y_out, int B, int H, int W, int nx, int ny, hipStream_t st) {
+    return bd.attn.channels == 24 ? launch_win24_half(bd, mode, raw, pk, pk + pb, x_in, y_in, x_out, y_out, B, H, W, nx, ny, st)
+                                  : launch_win48_half(bd, mode, raw, pk, pk + pb, x_in, y_in, x_out, y_out, B, H, W, nx, ny, st);
 }
 
-// MLP half on window24_kernel<HID, 8, W24_MLP, raw>: tokens as flat lists.  Dual path: one list per stream.  Single path: the one
+// MLP half on window24_kernel / window48_kernel <HID, 8, MLP half, raw>: tokens as flat lists.  Dual path: one list per stream.  Single path: the one
 // list is split between the kernel's two stream slots (same weights).  SWF_ERR_UNSUPPORTED = shape not covered (the caller falls back).
 static int mlp_half24(int C, int hid, int raw, const swf_block_stream_params* px, const swf_block_stream_params* py, const float* x_in,
                       const float* y_in, float* x_out, float* y_out, int64_t N, void* workspace, size_t workspace_bytes, hipStream_t stream) {
-    const size_t pb = win24_half_packed_bytes(C, hid);
-    if (!pb || N <= 0 || N * 24 * 4 >= (int64_t(1) << 31) || !workspace || workspace_bytes < 2 * pb) return SWF_ERR_UNSUPPORTED;
+    const size_t pb = half_packed_bytes(C, hid);
+    if (!pb || N <= 0 || N * C * 4 >= (int64_t(1) << 31) || !workspace || workspace_bytes < 2 * pb) return SWF_ERR_UNSUPPORTED;
     swf_block_desc bd{};
-    bd.attn = swf_attn_desc{24, 8, 3, 8, 8, 0};
+    bd.attn = swf_attn_desc{C, 8, C / 8, 8, 8, 0};
     bd.hidden = hid; bd.cross = 0; bd.precision = SWF_PREC_FAST;
     swf_block_stream_params sx = *px, sy = py ? *py : *px;
     sx.attn = swf_attn_params{}; sy.attn = swf_attn_params{};
     sx.ln1 = sy.ln1 = swf_norm{nullptr, nullptr};
     if (raw) sx.ln2 = sy.ln2 = swf_norm{nullptr, nullptr};
     char* pk = static_cast<char*>(workspace);
-    SWF_TRY(pack_win24(bd, sx, sy, pk, pk + pb, stream));
-    if (py) return launch_win24_half(bd, WIN24_HALF_MLP, raw, pk, pk + pb, x_in, y_in, x_out, y_out, 1, 1, 1, (int)N, (int)N, stream);
+    SWF_TRY(half_pack(bd, sx, sy, pk, pb, stream));
+    if (py) return half_launch(bd, WIN24_HALF_MLP, raw, pk, pb, x_in, y_in, x_out, y_out, 1, 1, 1, (int)N, (int)N, stream);
     const int64_t n0 = std::min<int64_t>(N, ((N + 1) / 2 + 63) / 64 * 64);
-    return launch_win24_half(bd, WIN24_HALF_MLP, raw, pk, pk + pb, x_in, x_in + n0 * 24, x_out, x_out + n0 * 24, 1, 1, 1, (int)n0, (int)(N - n0), stream);
+    return half_launch(bd, WIN24_HALF_MLP, raw, pk, pb, x_in, x_in + n0 * C, x_out, x_out + n0 * C, 1, 1, 1, (int)n0, (int)(N - n0), stream);
 }
 
 size_t swf_window_attention_workspace_bytes(const swf_attn_desc* desc, int32_t B, int32_t H, int32_t W) {
     if (!desc || B <= 0 || H <= 0 || W <= 0) return 0;
-    return std::max(attention_generic_ws(*desc, 1, B, H, W), 2 * win24_half_packed_bytes(desc->channels, 96) + 512);
+    return std::max(attention_generic_ws(*desc, 1, B, H, W), 2 * half_packed_bytes(desc->channels, half_attn_hidden(desc->channels)) + 512);
 }
 
 static int window_attention_impl(const swf_attn_desc* desc, int precision, const swf_attn_params* p, const float* q, const float* k,
@@ -1015,16 +1027,17 @@ static int window_attention_impl(const swf_attn_desc* desc, int precision, const
     if (!p || !q || !k || !v || !out) return fail(SWF_ERR_NULL, "window_attention: NULL tensor or params");
     if (!p->q.weight || !p->k.weight || !p->v.weight || !p->proj.weight || !p->bias_table)
         return fail(SWF_ERR_NULL, "window_attention: NULL weight");
-    const size_t pb24 = win24_half_packed_bytes(desc->channels, 96);
-    if (precision == SWF_PREC_FAST && k == v && !residual && half24_attn_shape(*desc, H, W) && (int64_t)B * H * W * 24 * 4 < (int64_t(1) << 31) &&
-        workspace && workspace_bytes >= 2 * pb24 && out != q && out != k) {
-        // window24_kernel<.., W24_ATTN, RAW>: stream 0 = the queries and the output, stream 1 = the key / value tensor
-        swf_block_desc bd{*desc, 96, 1, SWF_PREC_FAST};
+    const int hid_a = half_attn_hidden(desc->channels);
+    const size_t pbh = half_packed_bytes(desc->channels, hid_a);
+    if (precision == SWF_PREC_FAST && k == v && !residual && half_attn_shape(*desc, H, W) && (int64_t)B * H * W * desc->channels * 4 < (int64_t(1) << 31) &&
+        pbh && workspace && workspace_bytes >= 2 * pbh && out != q && out != k) {
+        // window24/48_kernel<.., attention half, RAW>: stream 0 = the queries and the output, stream 1 = the key / value tensor
+        swf_block_desc bd{*desc, hid_a, 1, SWF_PREC_FAST};
         swf_block_stream_params sp{};
         sp.attn = *p;
         char* pk = static_cast<char*>(workspace);
-        SWF_TRY(pack_win24(bd, sp, sp, pk, pk + pb24, as_stream(stream)));
-        return launch_win24_half(bd, WIN24_HALF_ATTN, 1, pk, pk + pb24, q, k, out, nullptr, B, H, W, 0, 0, as_stream(stream));
+        SWF_TRY(half_pack(bd, sp, sp, pk, pbh, as_stream(stream)));
+        return half_launch(bd, WIN24_HALF_ATTN, 1, pk, pbh, q, k, out, nullptr, B, H, W, 0, 0, as_stream(stream));
     }
     Carver ws(workspace, workspace_bytes);
     const swf_attn_params* prm[2] = {p, nullptr};
@@ -1052,28 +1065,28 @@ int swf_window_attention_fwd_prec(const swf_attn_desc* desc, int32_t precision, 
 size_t swf_basic_block_workspace_bytes(const swf_block_desc* desc, int32_t B, int32_t H, int32_t W) {
     if (!desc || B <= 0 || H <= 0 || W <= 0) return 0;
     return std::max(std::max(block_generic_ws(desc, 2, B, H, W), window_block_workspace_bytes(*desc, B, H, W)),
-                    2 * std::max(win24_half_packed_bytes(desc->attn.channels, 96), win24_half_packed_bytes(desc->attn.channels, desc->hidden)) + 512);
+                    2 * std::max(half_packed_bytes(desc->attn.channels, half_attn_hidden(desc->attn.channels)), half_packed_bytes(desc->attn.channels, desc->hidden)) + 512);
 }
 
 int swf_attn_halfblock_fwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                            const float* x_in, const float* y_in, float* x_out, float* y_out, int32_t B, int32_t H, int32_t W,
                            void* workspace, size_t workspace_bytes, swf_stream_t stream) {
     SWF_TRY(check_block(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, true, false));
-    const size_t pb24 = win24_half_packed_bytes(desc->attn.channels, 96);
-    if (desc->precision == SWF_PREC_FAST && half24_attn_shape(desc->attn, H, W) && (int64_t)B * H * W * 24 * 4 < (int64_t(1) << 31) &&
-        workspace && workspace_bytes >= 2 * pb24) {
-        // window24_kernel<.., W24_ATTN>: LN1 + Q/K/V + attention + projection + residual of both streams in one launch.  A single-path
+    const int hid_a = half_attn_hidden(desc->attn.channels);
+    const size_t pbh = half_packed_bytes(desc->attn.channels, hid_a);
+    if (desc->precision == SWF_PREC_FAST && half_attn_shape(desc->attn, H, W) && (int64_t)B * H * W * desc->attn.channels * 4 < (int64_t(1) << 31) &&
+        pbh && workspace && workspace_bytes >= 2 * pbh) {
+        // window24/48_kernel<.., attention half>: LN1 + Q/K/V + attention + projection + residual of both streams in one launch.  A single-path
         // block runs its stream as stream 0; stream 1 mirrors it with its stores dropped.
         swf_block_desc bd = *desc;
-        bd.hidden = 96;
+        bd.hidden = hid_a;
         bd.cross = desc->cross && py;   // a single path ignores cross (a002:83)
         swf_block_stream_params sx = *px, sy = py ? *py : *px;
         sx.fc1 = sx.fc2 = swf_linear{nullptr, nullptr}; sy.fc1 = sy.fc2 = swf_linear{nullptr, nullptr};
         sx.ln2 = sy.ln2 = swf_norm{nullptr, nullptr};
         char* pk = static_cast<char*>(workspace);
-        SWF_TRY(pack_win24(bd, sx, sy, pk, pk + pb24, as_stream(stream)));
-        return launch_win24_half(bd, WIN24_HALF_ATTN, 0, pk, pk + pb24, x_in, py ? y_in : x_in, x_out, py ? y_out : nullptr, B, H, W, 0, 0,
-                                 as_stream(stream));
+        SWF_TRY(half_pack(bd, sx, sy, pk, pbh, as_stream(stream)));
+        return half_launch(bd, WIN24_HALF_ATTN, 0, pk, pbh, x_in, py ? y_in : x_in, x_out, py ? y_out : nullptr, B, H, W, 0, 0, as_stream(stream));
     }
     Carver ws(workspace, workspace_bytes);
     return attn_halfblock_generic(desc, px, py, x_in, y_in, x_out, y_out, B, H, W, ws, as_stream(stream));
@@ -1096,7 +1109,7 @@ size_t swf_mlp_workspace_bytes(int32_t precision, int64_t tokens, int32_t channe
     if (tokens <= 0 || channels <= 0 || hidden <= 0) return 0;
     size_t generic = carve_bytes({tokens * hidden}) + std::max(swf_linear_workspace_bytes(precision, tokens, channels, hidden),
                                                                swf_linear_workspace_bytes(precision, tokens, hidden, channels));
-    return std::max(generic, 2 * win24_half_packed_bytes(channels, hidden) + 512);
+    return std::max(generic, 2 * half_packed_bytes(channels, hidden) + 512);
 }
 
 int swf_mlp_fwd(int32_t precision, const swf_block_stream_params* px, const swf_block_stream_params* py, const float* x_in, const float* y_in,

@@ -170,30 +170,34 @@ def test_inner_modules_compose_like_the_block(precision):
     _close_(mx, rx); _close_(my, ry)
 
 
-_HALVES = [  # level-0 width through the fused half-block kernels (window24_kernel<.., W24_ATTN / W24_MLP>): win, hidden, dual, cross, shift, (B,H,W)
-    (8, 96, True, True, True, (2, 16, 24)),
-    (8, 96, True, False, False, (1, 24, 8)),
-    (8, 96, False, False, True, (1, 8, 16)),      # single-path block: one stream through the two-stream kernel
-    (7, 96, True, True, True, (1, 14, 21)),
-    (8, 4, True, True, False, (3, 8, 8)),         # decoder width: hidden 4
+_HALVES = [  # levels 0 / 1 through the fused half-block kernels (window24 / window48_kernel<.., attention half / MLP half>): C, win, hidden, dual, cross, shift, (B,H,W)
+    (24, 8, 96, True, True, True, (2, 16, 24)),
+    (24, 8, 96, True, False, False, (1, 24, 8)),
+    (24, 8, 96, False, False, True, (1, 8, 16)),      # single-path block: one stream through the two-stream kernel
+    (24, 7, 96, True, True, True, (1, 14, 21)),
+    (24, 8, 4, True, True, False, (3, 8, 8)),         # decoder width: hidden 4
+    (48, 8, 192, True, True, True, (2, 16, 24)),
+    (48, 8, 96, True, False, True, (1, 8, 24)),       # decoder width
+    (48, 8, 192, False, False, False, (3, 8, 8)),
+    (48, 7, 192, True, True, True, (1, 21, 14)),
 ]
 
 
-@pytest.mark.parametrize("case", _HALVES, ids=[f"w{c[0]}_hid{c[1]}_dual{int(c[2])}_c{int(c[3])}s{int(c[4])}" for c in _HALVES])
+@pytest.mark.parametrize("case", _HALVES, ids=[f"C{c[0]}_w{c[1]}_hid{c[2]}_dual{int(c[3])}_c{int(c[4])}s{int(c[5])}" for c in _HALVES])
 def test_standalone_halves_level0_fast_vs_oracle(case):
-    """a004 around a002 / a003 and the bare a002 / a003 / a001 modules at C = 24 in the fast tier: each is ONE launch of the level-0
+    """a004 around a002 / a003 and the bare a002 / a003 / a001 modules at C = 24 / 48 in the fast tier: each is ONE launch of the level's
     block kernel with the other half compiled out; compared with the oracle's functions of the same names."""
-    win, hid, dual, cross, shift, (b, h, w) = case
-    m = BasicBlock(24, 8, 3, (win, win), shift, dual, cross, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
+    C_, win, hid, dual, cross, shift, (b, h, w) = case
+    m = BasicBlock(C_, 8, C_ // 8, (win, win), shift, dual, cross, True, 0.0, 0.0, hid, _elu(), 0.0).eval()
     load_recipe_into(m, seed=31, flavor="stress")
     sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
-    x, y = G.randn((b, 24, h, w), 701), G.randn((b, 24, h, w), 702)
+    x, y = G.randn((b, C_, h, w), 701), G.randn((b, C_, h, w), 702)
     m.to(DEV)
     for sub in m.modules():
         if hasattr(sub, "precision"):
             sub.precision = "fast"
     xd, yd = x.to(DEV), (y.to(DEV) if dual else None)
-    kw = dict(num_heads=8, dims_per_head=3, window_size=(win, win), use_cyclic_shift=shift)
+    kw = dict(num_heads=8, dims_per_head=C_ // 8, window_size=(win, win), use_cyclic_shift=shift)
     chk = lambda got, ref: _close(got, ref, TOL_FAST_L2, TOL_FAST_MAX)
     if dual:
         rx, ry = O.auto_path_win_att(sd, "auto_path_win_att.", x, y, cross=cross, **kw)
@@ -203,7 +207,7 @@ def test_standalone_halves_level0_fast_vs_oracle(case):
         ax, ay = m.auto_path_mlp(xd, yd)
         chk(ax, rx); chk(ay, ry)
         # the two pre-norm residual halves compose to the block (a005:138-141)
-        bx, by = O.basic_block(sd, "", x, y, cross=cross, shift=shift, num_heads=8, dims_per_head=3, window_size=(win, win))
+        bx, by = O.basic_block(sd, "", x, y, cross=cross, shift=shift, num_heads=8, dims_per_head=C_ // 8, window_size=(win, win))
         x1, y1 = m.stage_1(xd, yd)
         x2, y2 = m.stage_2(x1, y1)
         chk(x2, bx); chk(y2, by)

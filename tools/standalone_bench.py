@@ -23,16 +23,18 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
+    ap.add_argument("--channels", type=int, default=24, help="24 (level 0, hidden 96) or 48 (level 1, hidden 192)")
     a = ap.parse_args()
     entry.build()
     from swin_unet_image_fusion_amd import BasicBlock, _lib as L, load_recipe_into
     from swin_unet_image_fusion_amd.modules import _ptr, _stream, _workspace
     torch.set_grad_enabled(False)
     dev = torch.device("cuda:0")
-    blk = BasicBlock(24, 8, 3, (8, 8), True, True, True, True, 0.0, 0.0, 96, nn.ELU(inplace=True), 0.0).eval()
+    c, hid = a.channels, 4 * a.channels
+    blk = BasicBlock(c, 8, c // 8, (8, 8), True, True, True, True, 0.0, 0.0, hid, nn.ELU(inplace=True), 0.0).eval()
     load_recipe_into(blk, seed=0)
     blk.to(dev)
-    b, h, w, c = a.batch, a.size, a.size, 24
+    b, h, w = a.batch, a.size, a.size
     n = b * h * w
     x, y = torch.randn(b, h, w, c, device=dev), torch.randn(b, h, w, c, device=dev)
     ox, oy = torch.empty_like(x), torch.empty_like(y)
@@ -54,12 +56,12 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / a.iters * 1e3   # us
 
-    out = {"shape": f"B={b} {h}x{w} map, C=24, 8 heads x 3, 8x8 windows (shifted), hidden 96; NHWC fp32 in HBM", "unit": "us per call", "entries": {}}
+    out = {"shape": f"B={b} {h}x{w} map, C={c}, 8 heads x {c // 8}, 8x8 windows (shifted), hidden {hid}; NHWC fp32 in HBM", "unit": "us per call", "entries": {}}
     for prec_name, prec in (("fast", L.PREC_FAST), ("fp32", L.PREC_FP32)):
         bdesc = blk._desc(prec_name)
         ws, wsn = _workspace(max(lib.swf_window_attention_workspace_bytes(C.byref(adesc), b, h, w),
                                  lib.swf_basic_block_workspace_bytes(C.byref(bdesc), b, h, w),
-                                 lib.swf_mlp_workspace_bytes(prec, n, c, 96)), dev)
+                                 lib.swf_mlp_workspace_bytes(prec, n, c, hid)), dev)
         calls = {
             # cross form: q from one stream, k = v from the other (a002:67-82)
             "WindowAttention.forward (swf_window_attention_fwd_prec)": (
@@ -70,10 +72,10 @@ def main():
                 4 * n * c * 4 + 2 * (4 * c * c + 6 * c + tbl) * 4),
             "AddAndLayerNorm(AutoPathMLP) both streams (swf_mlp_halfblock_fwd)": (
                 lambda: L.check(lib.swf_mlp_halfblock_fwd(C.byref(bdesc), C.byref(px), C.byref(py), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy), b, h, w, ws, wsn, st)),
-                4 * n * c * 4 + 2 * (2 * c * 96 + 96 + 3 * c) * 4),
+                4 * n * c * 4 + 2 * (2 * c * hid + hid + 3 * c) * 4),
             "AutoPathMLP.forward both streams (swf_mlp_fwd)": (
-                lambda: L.check(lib.swf_mlp_fwd(prec, C.byref(px), C.byref(py), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy), n, c, 96, ws, wsn, st)),
-                4 * n * c * 4 + 2 * (2 * c * 96 + 96 + c) * 4),
+                lambda: L.check(lib.swf_mlp_fwd(prec, C.byref(px), C.byref(py), _ptr(x), _ptr(y), _ptr(ox), _ptr(oy), n, c, hid, ws, wsn, st)),
+                4 * n * c * 4 + 2 * (2 * c * hid + hid + c) * 4),
         }
         for name, (fn, alg_bytes) in calls.items():
             us = timed(fn)
