@@ -13,4 +13,10 @@ int launch_win96(const swf_block_desc& d, const void* packed_x, const void* pack
                  float* x_out, float* y_out, int B, int H, int W, hipStream_t stream, const void* next_packed_x,
                  const void* next_packed_y, size_t next_bytes);
 
+// the two halves of the block as launches of their own (mode 1 = attention half, 2 = MLP half; raw = 1: no LayerNorm, no residual);
+// same contract as launch_win24_half (kernels_win24.h)
+size_t win96_half_packed_bytes(int channels, int hidden);
+int launch_win96_half(const swf_block_desc& d, int mode, int raw, const void* packed_x, const void* packed_y, const float* x_in,
+                      const float* y_in, float* x_out, float* y_out, int B, int H, int W, int ntok_x, int ntok_y, hipStream_t stream);
+
 }  // namespace swf

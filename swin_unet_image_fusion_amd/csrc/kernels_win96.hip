@@ -50,11 +50,16 @@ struct G96 {
 
 struct Win96Args {
     const float* in[2];
-    float* out[2];
+    float* out[2];       // half-block modes: a NULL out[s] drops that stream's stores
     const char* packed[2];
     const char* warm[2];
     int B, H, W, shift, cross, warm_bytes;
+    int ntok[2];         // MLP half (W96_MLP): token count of each stream's flat token list
 };
+
+// launch modes of window96_kernel: the whole block, or one half of it as a launch of its own (kernels_win24.hip: W24_*; RAW = no
+// LayerNorm, no residual; RAW attention: stream 0 = queries and output, stream 1 = key / value tensor)
+constexpr int W96_BLOCK = 0, W96_ATTN = 1, W96_MLP = 2;
 
 // LayerNorm (eps 1e-5, biased variance) of the lane's token: 48 of its 96 channels sit in this lane (three tiles x 16 registers),
 // the other 48 in lane l ^ 32.  Output: the six k-step fragments of the next linear layer.
@@ -86,6 +91,18 @@ __device__ __forceinline__ void layernorm96(const f32x16 (&x)[3], const float* v
             n[4 * a + 2] = (x[T][4 * a + 2] - mean) * rstd * g.z + b.z;
             n[4 * a + 3] = (x[T][4 * a + 3] - mean) * rstd * g.w + b.w;
         }
+        split8(n, xh[2 * T], xl[2 * T]);
+        split8(n + 8, xh[2 * T + 1], xl[2 * T + 1]);
+    }
+}
+
+// RAW modes: the un-normalised row as the operand fragments of the next linear layer
+__device__ __forceinline__ void raw96(const f32x16 (&x)[3], u32x4 (&xh)[6], u32x4 (&xl)[6]) {
+#pragma unroll
+    for (int T = 0; T < 3; ++T) {
+        float n[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) n[i] = x[T][i];
         split8(n, xh[2 * T], xl[2 * T]);
         split8(n + 8, xh[2 * T + 1], xl[2 * T + 1]);
     }
@@ -149,10 +166,12 @@ __device__ __forceinline__ void attention96(const u32x4* ksrc, const u32x4* vsrc
 
 // WS = window side, 8 or 7 (the reference's default): 7x7 windows run on the 8x8 token grid, padding tokens beyond the buffer
 // range (reads 0, stores dropped) and -inf in the packed bias matrix as keys (kernels_win24.hip).
-template <int HID, int WS>
+template <int HID, int WS, int MODE = W96_BLOCK, bool RAW = false>
 __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
     using G = G96<HID>;
     static_assert(WS == 7 || WS == 8, "window side");
+    static_assert(!RAW || MODE != W96_BLOCK, "RAW belongs to the half-block modes");
+    constexpr bool ATT = MODE != W96_MLP, MLP = MODE != W96_ATTN;
     extern __shared__ __attribute__((aligned(16))) char smem96[];
     u32x4* kimg = reinterpret_cast<u32x4*>(smem96 + G::l_k);   // [stream][key tile][vch tile][k-step][lane]
     u32x4* vimg = reinterpret_cast<u32x4*>(smem96 + G::l_v);   // [stream][vch tile][pv-step][lane]
@@ -160,16 +179,16 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int ws = wave >> 1, qb = wave & 1, r = lane & 31, hf = lane >> 5;
-    const int H = args.H, W = args.W, nwx = W / WS, nwy = H / WS, npi = nwx * nwy;
-    const int nwin = args.B * npi;
+    const int H = args.H, W = args.W, nwx = ATT ? W / WS : 1, nwy = ATT ? H / WS : 1, npi = nwx * nwy;
+    const int nwin = ATT ? args.B * npi : (max(args.ntok[0], args.ntok[1]) + 63) / 64;   // MLP half: 64 tokens of the flat list per step
     const int sh = args.shift ? WS / 2 : 0;
     const int kvs = args.cross ? 1 - ws : ws;   // the stream whose attention reads this wave's tokens as keys (a002:67-82)
 
     const __amdgpu_buffer_rsrc_t wrs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[ws])), 0, (int)G::p_total, 0x00020000);
     const __amdgpu_buffer_rsrc_t krs = __builtin_amdgcn_make_buffer_rsrc(const_cast<char*>(uniform_ptr(args.packed[kvs])), 0, (int)G::p_total, 0x00020000);
-    const int act_bytes = args.B * H * W * 96 * 4;   // < 2^31 (launch_win96)
+    const int act_bytes = ATT ? args.B * H * W * 96 * 4 : args.ntok[ws] * 96 * 4;   // < 2^31 (launch_win96)
     const __amdgpu_buffer_rsrc_t irs = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(uniform_ptr(args.in[ws])), 0, act_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, act_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t ors = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr(args.out[ws]), 0, (MODE == W96_BLOCK || args.out[ws]) ? act_bytes : 0, 0x00020000);
     const unsigned loff = (unsigned)lane * 16u;
     auto WF = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, loff, f * 1024, 0)); };   // own stream: Q, proj, MLP
     auto WK = [&](int f) { return __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(krs, loff, f * 1024, 0)); };   // K / V weights
@@ -188,7 +207,14 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
         int oy = wy * WS + ty + sh, ox = wx * WS + tx + sh;
         oy = oy >= H ? oy - H : oy;
         ox = ox >= W ? ox - W : ox;
-        const unsigned tokoff = (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 96 + 4 * hf) * 4) : 0x80000000u;
+        const unsigned tokoff = [&]() -> unsigned {
+            if constexpr (ATT) {
+                return (WS == 8 || (ty < WS && tx < WS)) ? (unsigned)((((b * H + oy) * W + ox) * 96 + 4 * hf) * 4) : 0x80000000u;
+            } else {   // flat token list; past the stream's end: out of range (reads 0, stores dropped)
+                const int tok = 64 * win + 32 * qb + r;
+                return tok < args.ntok[ws] ? (unsigned)((tok * 96 + 4 * hf) * 4) : 0x80000000u;
+            }
+        }();
         // the lane's 48 channels: float4 a (0..11) = channels 8a + 4hf .. +3 = registers 4(a & 3) .. of tile a >> 2
         auto load_rows = [&](f32x16 (&x)[3]) {
 #pragma unroll
@@ -198,6 +224,8 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
             }
         };
 
+        f32x16 res[3];
+        if constexpr (ATT) {
         // ---- LN1, then Q (own stream's weights), K and V (weights of the stream that attends to these tokens) ----
         u32x4 qf[4][2];
         {
@@ -223,7 +251,8 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
                     fill_vectors<G::VSTREAM / 4, 256>(lvec, args.packed[0] + G::p_vec, args.packed[1] + G::p_vec, tid);
                     __syncthreads();
                 }
-                layernorm96(x, vec, G::V_LN1G, G::V_LN1B, xh, xl);
+                if constexpr (RAW) raw96(x, xh, xl);
+                else layernorm96(x, vec, G::V_LN1G, G::V_LN1B, xh, xl);
             }
             f32x16 acc = zero16;
 #pragma unroll
@@ -233,14 +262,20 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
                 if (hp + 1 < 24) req(hp + 1, wq[(hp + 1) & 1]);
                 SWF_WF_FENCE();
                 const u32x4 (&w)[6] = wq[hp & 1];
+                // (wave-uniform) RAW attention: the key / value stream has no queries, the query stream's tokens are nobody's keys; the
+                // barrier of the first K tile is every wave's
+                const bool skip = RAW && (m == 0 ? ws == 1 : ws == 0);
+                if (skip && hp == 9 && win != (int)blockIdx.x) __syncthreads();
                 if (half == 0) acc = zero16;
+                if (!skip) {
 #pragma unroll
                 for (int s = 0; s < 3; ++s) {
                     const int ks = 3 * half + s;
                     acc = m < 2 ? mma3(w[2 * s], w[2 * s + 1], xh[ks], xl[ks], acc)      // [virtual channel][token]
                                 : mma3(xh[ks], xl[ks], w[2 * s], w[2 * s + 1], acc);     // V: [token][virtual channel]
                 }
-                if (half == 1) {
+                }
+                if (half == 1 && !skip) {
                     float t[16];
                     if (m < 2) {
                         const float* bsrc = m == 0 ? vec + G::V_BQ : veck + G::V_BK;
@@ -279,6 +314,7 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
                 bias[kt][4 * a] = v.x; bias[kt][4 * a + 1] = v.y; bias[kt][4 * a + 2] = v.z; bias[kt][4 * a + 3] = v.w;
             }
         __syncthreads();   // K / V^T images of both streams complete
+        if (RAW && ws == 1) continue;   // RAW: the key / value stream is done with this window
 
         // ---- attention of the wave's 32 queries, 8 heads (shift mask: kernels_win24.hip) ----
         f32x16 o[4];
@@ -296,14 +332,14 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
         }
 
         // ---- normalise (denominator: lane half 1, register 8sp + 4 of the head's tile), output projection + bias + residual ----
-        f32x16 res[3];
         u32x4 wp[2][6];   // projection fragments of a k-step: [out tile][hi, lo]; two sets, the first requested under the normalisation
         auto reqp = [&](int ks, u32x4 (&dst)[6]) {
 #pragma unroll
             for (int To = 0; To < 3; ++To) { dst[2 * To] = WF(G::F_P + (To * 8 + ks) * 2); dst[2 * To + 1] = WF(G::F_P + (To * 8 + ks) * 2 + 1); }
         };
         SWF_WF_FENCE();
-        load_rows(res);
+        if constexpr (RAW) { res[0] = zero16; res[1] = zero16; res[2] = zero16; }
+        else load_rows(res);
         reqp(0, wp[0]);
         SWF_WF_FENCE();
         {
@@ -331,8 +367,16 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
             }
         }
 
+        } else {   // MLP half: the rows as they are; the fp32 vectors once per launch
+            load_rows(res);
+            if (win == (int)blockIdx.x) {
+                fill_vectors<G::VSTREAM / 4, 256>(lvec, args.packed[0] + G::p_vec, args.packed[1] + G::p_vec, tid);
+                __syncthreads();
+            }
+        }
+
         // ---- LN2, MLP: fc1 tile -> ELU -> split -> two k-steps of fc2 accumulating onto the residual ----
-        {
+        if constexpr (MLP) {
             u32x4 w1[12];
             auto req1 = [&](int tI) {
 #pragma unroll
@@ -341,7 +385,8 @@ __global__ __launch_bounds__(256, 2) void window96_kernel(Win96Args args) {
             req1(0);   // in flight during LN2
             SWF_WF_FENCE();
             u32x4 xh[6], xl[6];
-            layernorm96(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
+            if constexpr (RAW) { raw96(res, xh, xl); res[0] = zero16; res[1] = zero16; res[2] = zero16; }   // AutoPathMLP.forward: no norm, no residual
+            else layernorm96(res, vec, G::V_LN2G, G::V_LN2B, xh, xl);
 #pragma unroll 1
             for (int tI = 0; tI < G::NT1; ++tI) {
                 SWF_WF_FENCE();
@@ -1061,7 +1106,9 @@ __global__ __launch_bounds__(256) void pack96_kernel(Pack96Args a) {
     char* dst = a.dst[st];
     const int gtid = blockIdx.x * blockDim.x + threadIdx.x, gsz = gridDim.x * blockDim.x;
     const float qscale = kLog2e / sqrtf(12.0f);   // d^-0.5 (a001:32-34) and exp -> exp2
-    auto bia = [](const swf_linear& l, int n) { return l.bias ? l.bias[n] : 0.f; };
+    // (the half-block entries pack only the half they run: a missing layer packs as zeros, a missing norm as identity)
+    auto bia = [](const swf_linear& l, int n) { return (l.weight && l.bias) ? l.bias[n] : 0.f; };
+    auto wgt = [](const swf_linear& l, int i) { return l.weight ? l.weight[i] : 0.f; };
 
     for (int idx = gtid; idx < G::NFRAG * 512; idx += gsz) {
         const int f = idx >> 9, lane = (idx >> 3) & 63, e = idx & 7, r = lane & 31, hf = lane >> 5;
@@ -1072,22 +1119,22 @@ __global__ __launch_bounds__(256) void pack96_kernel(Pack96Args a) {
             const int k = kslot(s, hf, e), vch = 32 * T + r, head = vch >> 4, c = vch & 15;
             const swf_linear& l = m == 0 ? p.attn.q : m == 1 ? p.attn.k : p.attn.v;
             if (c < 12) {
-                val = l.weight[(head * 12 + c) * 96 + k];
+                val = wgt(l, (head * 12 + c) * 96 + k);
                 if (m == 0) val *= qscale;
             }
         } else if (f < G::F_W1) {   // projection: row = output channel 32To + r; k-step = head, element = the head's row in accumulator order;
                                     // head 0's row 12 (= 1 after normalisation) carries the bias
             const int g = (f - G::F_P) >> 1, ks = g & 7, To = g >> 3;
             const int n = 32 * To + r, row = rho(e, hf);   // rho(8 * 0 + e, hf) of a 16-row head: (e & 3) + 8 (e >> 2) + 4 hf
-            val = row < 12 ? p.attn.proj.weight[n * 96 + ks * 12 + row] : ((ks == 0 && row == 12) ? bia(p.attn.proj, n) : 0.f);
+            val = row < 12 ? wgt(p.attn.proj, n * 96 + ks * 12 + row) : ((ks == 0 && row == 12) ? bia(p.attn.proj, n) : 0.f);
         } else if (f < G::F_W2) {   // fc1 (exp2 units): row = hidden unit
             const int g = (f - G::F_W1) >> 1, s = g % 6, tI = g / 6;
             const int k = kslot(s, hf, e), hid = 32 * tI + r;
-            val = p.fc1.weight[hid * 96 + k] * kLog2e;
+            val = wgt(p.fc1, hid * 96 + k) * kLog2e;
         } else {   // fc2 (x ln 2): row = output channel; k = hidden unit in accumulator order
             const int g = (f - G::F_W2) >> 1, u = g % G::KU, To = g / G::KU;
             const int n = 32 * To + r, hid = kslot(u, hf, e);
-            val = p.fc2.weight[n * HID + hid] * kLn2;
+            val = wgt(p.fc2, n * HID + hid) * kLn2;
         }
         const bf16 hi = (bf16)val;
         reinterpret_cast<bf16*>(dst)[idx] = hl ? (bf16)(val - (float)hi) : hi;
@@ -1100,7 +1147,8 @@ __global__ __launch_bounds__(256) void pack96_kernel(Pack96Args a) {
             if (j < G::V_BQ) {   // 48-entry vectors: entry k = register index (tile k >> 4, register k & 15)
                 const int which = j / 48, k = j % 48;
                 const int c = 32 * (k >> 4) + rho(k & 15, hf);
-                v = which == 0 ? p.ln1.gamma[c] : which == 1 ? p.ln1.beta[c] : which == 2 ? p.ln2.gamma[c] : which == 3 ? p.ln2.beta[c] : bia(p.fc2, c);
+                v = which == 0 ? (p.ln1.gamma ? p.ln1.gamma[c] : 1.f) : which == 1 ? (p.ln1.beta ? p.ln1.beta[c] : 0.f)
+                  : which == 2 ? (p.ln2.gamma ? p.ln2.gamma[c] : 1.f) : which == 3 ? (p.ln2.beta ? p.ln2.beta[c] : 0.f) : bia(p.fc2, c);
             } else if (j < G::V_B1) {   // Q / K bias in accumulator order; K's spare row 13 is the constant 1 (the -max slot)
                 const int isk = j >= G::V_BK, k = j - (isk ? G::V_BK : G::V_BQ), vch = 32 * (k >> 4) + rho(k & 15, hf);
                 const int head = vch >> 4, c = vch & 15;
@@ -1118,6 +1166,7 @@ __global__ __launch_bounds__(256) void pack96_kernel(Pack96Args a) {
     }
     // relative-position bias (a001:113-144), exp2 units: [query block][key tile][register / 4][lane][register % 4]
     float* bm = reinterpret_cast<float*>(dst + G::p_bias);
+    if (!p.attn.bias_table) return;   // MLP half: the bias section is never read
     if (a.ws == 16) {   // [distance kt - qb + 7][register / 4][lane][register % 4]; a tile = two window rows of 16
         for (int i = gtid; i < 15 * 16 * 64; i += gsz) {
             const int j = i & 3, lane = (i >> 2) & 63, a4 = (i >> 8) & 3, d = i >> 10;
@@ -1188,6 +1237,48 @@ static int launch96x8_t(const Win96Args& a, int grid, hipStream_t stream) {
     if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window96x8): %s", hipGetErrorString(attr_err));
     hipLaunchKernelGGL((window96x8_kernel<HID, WS>), dim3(grid), dim3(512), lds, stream, a);
     return check_launch("window96x8");
+}
+
+size_t win96_half_packed_bytes(int channels, int hidden) {
+    if (channels != 96 || (hidden != 384 && hidden != 192)) return 0;
+    return align_up(hidden == 384 ? G96<384>::p_total : G96<192>::p_total, 256);
+}
+
+template <int HID, int WS, int MODE, bool RAW>
+static int launch96_half_t(const Win96Args& a, int grid, hipStream_t stream) {
+    constexpr int lds = (int)G96<HID>::l_total;
+    static hipError_t attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(&window96_kernel<HID, WS, MODE, RAW>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    if (attr_err != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(window96 half): %s", hipGetErrorString(attr_err));
+    hipLaunchKernelGGL((window96_kernel<HID, WS, MODE, RAW>), dim3(grid), dim3(256), lds, stream, a);
+    return check_launch("window96 (half block)");
+}
+
+// Half-block launches (8x8 / 7x7 windows) on the four-wave kernel: see launch_win24_half (kernels_win24.hip) for the contract.
+int launch_win96_half(const swf_block_desc& d, int mode, int raw, const void* packed_x, const void* packed_y, const float* x_in,
+                      const float* y_in, float* x_out, float* y_out, int B, int H, int W, int ntok_x, int ntok_y, hipStream_t stream) {
+    const int wsd = d.attn.win_h;
+    if (mode != W96_ATTN && mode != W96_MLP) return fail(SWF_ERR_UNSUPPORTED, "win96_half: mode %d", mode);
+    if (d.attn.channels != 96 || (d.hidden != 384 && d.hidden != 192)) return fail(SWF_ERR_UNSUPPORTED, "win96_half: shape not covered");
+    Win96Args a{};
+    a.in[0] = x_in; a.in[1] = y_in; a.out[0] = x_out; a.out[1] = y_out;
+    a.packed[0] = static_cast<const char*>(packed_x); a.packed[1] = static_cast<const char*>(packed_y);
+    a.B = B; a.H = H; a.W = W; a.shift = d.attn.shift; a.cross = d.cross; a.ntok[0] = ntok_x; a.ntok[1] = ntok_y;
+    int nwin;
+    if (mode == W96_ATTN) {
+        if (!win96_supported(d) || wsd == 16 || H % wsd || W % wsd) return fail(SWF_ERR_UNSUPPORTED, "win96_half: shape not covered");
+        if ((int64_t)B * H * W * 96 * 4 >= (int64_t(1) << 31)) return fail(SWF_ERR_UNSUPPORTED, "win96_half: map exceeds the 2 GB buffer window");
+        nwin = B * (H / wsd) * (W / wsd);
+    } else {
+        if ((int64_t)std::max(ntok_x, ntok_y) * 96 * 4 >= (int64_t(1) << 31) || ntok_x <= 0) return fail(SWF_ERR_UNSUPPORTED, "win96_half: token count");
+        nwin = (std::max(ntok_x, ntok_y) + 63) / 64;
+    }
+    const int grid = std::min(nwin, 2 * num_cus96());
+    if (mode == W96_ATTN) {   // the MLP geometry is irrelevant: the hidden-384 image layout serves
+        if (wsd == 8) return raw ? launch96_half_t<384, 8, W96_ATTN, true>(a, grid, stream) : launch96_half_t<384, 8, W96_ATTN, false>(a, grid, stream);
+        return raw ? launch96_half_t<384, 7, W96_ATTN, true>(a, grid, stream) : launch96_half_t<384, 7, W96_ATTN, false>(a, grid, stream);
+    }
+    if (d.hidden == 384) return raw ? launch96_half_t<384, 8, W96_MLP, true>(a, grid, stream) : launch96_half_t<384, 8, W96_MLP, false>(a, grid, stream);
+    return raw ? launch96_half_t<192, 8, W96_MLP, true>(a, grid, stream) : launch96_half_t<192, 8, W96_MLP, false>(a, grid, stream);
 }
 
 int launch_win96(const swf_block_desc& d, const void* packed_x, const void* packed_y, const float* x_in, const float* y_in,

@@ -12,6 +12,7 @@
 #include "kernels_window.h"
 #include "kernels_win24.h"
 #include "kernels_win48.h"
+#include "kernels_win96.h"
 #include "kernels_deep.h"
 #include "kernels_patch.h"
 #include "kernels_patchrr.h"
@@ -978,23 +979,27 @@ const char* swf_status_string(int status) {
 }
 
 // ---- fast tier of the stand-alone module entries at level-0 width (C = 24): the block kernel with the other half compiled out ----
-// (levels 0 and 1: C = 24 / 48, 8 heads of C / 8, 8x8 or 7x7 windows; hidden widths of the encoder / decoder blocks)
+// (levels 0-2: C = 24 / 48 / 96, 8 heads of C / 8, 8x8 or 7x7 windows; hidden widths of the encoder / decoder blocks)
 static bool half_attn_shape(const swf_attn_desc& a, int H, int W) {
-    return (a.channels == 24 || a.channels == 48) && a.heads == 8 && a.head_dim * 8 == a.channels && a.win_h == a.win_w &&
+    return (a.channels == 24 || a.channels == 48 || a.channels == 96) && a.heads == 8 && a.head_dim * 8 == a.channels && a.win_h == a.win_w &&
            (a.win_h == 8 || a.win_h == 7) && H % a.win_h == 0 && W % a.win_w == 0;
 }
-static int half_attn_hidden(int C) { return C == 24 ? 96 : 192; }   // the attention half runs on the wide-MLP image layout (fc sections unused)
-static size_t half_packed_bytes(int C, int hid) { return C == 24 ? win24_half_packed_bytes(C, hid) : C == 48 ? win48_half_packed_bytes(C, hid) : 0; }
+static int half_attn_hidden(int C) { return 4 * C; }   // the attention half runs on the wide-MLP image layout (fc sections unused)
+static size_t half_packed_bytes(int C, int hid) {
+    return C == 24 ? win24_half_packed_bytes(C, hid) : C == 48 ? win48_half_packed_bytes(C, hid) : C == 96 ? win96_half_packed_bytes(C, hid) : 0;
+}
 static int half_pack(const swf_block_desc& bd, const swf_block_stream_params& sx, const swf_block_stream_params& sy, char* pk, size_t pb, hipStream_t st) {
-    return bd.attn.channels == 24 ? pack_win24(bd, sx, sy, pk, pk + pb, st) : pack_win48(bd, sx, sy, pk, pk + pb, st);
+    return bd.attn.channels == 24 ? pack_win24(bd, sx, sy, pk, pk + pb, st)
+         : bd.attn.channels == 48 ? pack_win48(bd, sx, sy, pk, pk + pb, st) : pack_win96(bd, sx, sy, pk, pk + pb, st);
 }
 static int half_launch(const swf_block_desc& bd, int mode, int raw, const char* pk, size_t pb, const float* x_in, const float* y_in, float* x_out,
                        float* y_out, int B, int H, int W, int nx, int ny, hipStream_t st) {
     return bd.attn.channels == 24 ? launch_win24_half(bd, mode, raw, pk, pk + pb, x_in, y_in, x_out, y_out, B, H, W, nx, ny, st)
-                                  : launch_win48_half(bd, mode, raw, pk, pk + pb, x_in, y_in, x_out, y_out, B, H, W, nx, ny, st);
+         : bd.attn.channels == 48 ? launch_win48_half(bd, mode, raw, pk, pk + pb, x_in, y_in, x_out, y_out, B, H, W, nx, ny, st)
+                                  : launch_win96_half(bd, mode, raw, pk, pk + pb, x_in, y_in, x_out, y_out, B, H, W, nx, ny, st);
 }
 
-// MLP half on window24_kernel / window48_kernel <HID, 8, MLP half, raw>: tokens as flat lists.  Dual path: one list per stream.  Single path: the one
+// MLP half on window24 / window48 / window96_kernel <HID, 8, MLP half, raw>: tokens as flat lists.  Dual path: one list per stream.  Single path: the one
 // list is split between the kernel's two stream slots (same weights).  SWF_ERR_UNSUPPORTED = shape not covered (the caller falls back).
 static int mlp_half24(int C, int hid, int raw, const swf_block_stream_params* px, const swf_block_stream_params* py, const float* x_in,
                       const float* y_in, float* x_out, float* y_out, int64_t N, void* workspace, size_t workspace_bytes, hipStream_t stream) {

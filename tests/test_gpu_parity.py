@@ -180,12 +180,16 @@ _HALVES = [  # levels 0 / 1 through the fused half-block kernels (window24 / win
     (48, 8, 96, True, False, True, (1, 8, 24)),       # decoder width
     (48, 8, 192, False, False, False, (3, 8, 8)),
     (48, 7, 192, True, True, True, (1, 21, 14)),
+    (96, 8, 384, True, True, True, (1, 16, 24)),
+    (96, 8, 192, True, False, False, (2, 8, 8)),      # decoder width
+    (96, 8, 384, False, False, True, (1, 16, 8)),
+    (96, 7, 384, True, True, True, (1, 14, 14)),
 ]
 
 
 @pytest.mark.parametrize("case", _HALVES, ids=[f"C{c[0]}_w{c[1]}_hid{c[2]}_dual{int(c[3])}_c{int(c[4])}s{int(c[5])}" for c in _HALVES])
 def test_standalone_halves_level0_fast_vs_oracle(case):
-    """a004 around a002 / a003 and the bare a002 / a003 / a001 modules at C = 24 / 48 in the fast tier: each is ONE launch of the level's
+    """a004 around a002 / a003 and the bare a002 / a003 / a001 modules at C = 24 / 48 / 96 in the fast tier: each is ONE launch of the level's
     block kernel with the other half compiled out; compared with the oracle's functions of the same names."""
     C_, win, hid, dual, cross, shift, (b, h, w) = case
     m = BasicBlock(C_, 8, C_ // 8, (win, win), shift, dual, cross, True, 0.0, 0.0, hid, _elu(), 0.0).eval()

@@ -23,7 +23,7 @@ def main():
     ap.add_argument("--batch", type=int, default=16)
     ap.add_argument("--size", type=int, default=128)
     ap.add_argument("--iters", type=int, default=20)
-    ap.add_argument("--channels", type=int, default=24, help="24 (level 0, hidden 96) or 48 (level 1, hidden 192)")
+    ap.add_argument("--channels", type=int, default=24, help="24 / 48 / 96 (levels 0-2; hidden 4 x channels)")
     a = ap.parse_args()
     entry.build()
     from swin_unet_image_fusion_amd import BasicBlock, _lib as L, load_recipe_into
