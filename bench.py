@@ -29,7 +29,8 @@ from torch import nn  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8 TB/s HBM3E (spec)
 BYTES_PER_ELEM = 4          # the residual stream is stored fp32 (DESIGN.md "Data layout")
-TRAFFIC_FILE = "r02e_traffic.json"   # committed PMC summary of the level-0 block kernel (tools/pmc_traffic.sh)
+TRAFFIC_FILE = "r03_traffic.json"    # committed PMC summary of the level-0 block kernel (tools/pmc_levels.sh, tools/traffic_summary.py)
+PMC_LEVELS_FILE = "r03_pmc_levels.json"   # committed per-level counter summary (tools/pmc_levels.sh, tools/pmc_levels_summary.py)
 
 
 def parse():
@@ -117,7 +118,8 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
         with open(tj) as f:
             rec = json.load(f)
         traffic = rec.get("hbm_bytes_per_launch")
-        traffic_source = f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {rec.get('kernel', 'the level-0 block kernel')})"
+        traffic_source = (f"profiles/{TRAFFIC_FILE} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes of {rec.get('kernel', 'the level-0 block kernel')}, "
+                          f"build {rec.get('commit', '?')})")
     return {"bound": "hbm", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
             "frac": round(achieved / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": traffic_source,
             "kernel": kname,
@@ -167,6 +169,13 @@ def level_rooflines(model, ir, vis, step_ms, iters=5):
     tbl = (2 * wh - 1) * (2 * ww - 1)
     levels, patches = [], []
     total_bytes = 0
+    # MFMA / VALU busy fractions of each level's kernels from the committed counter passes (PMC cannot be read in-process: constants
+    # of the named file, collected on the build it names, for the default workload's encoder widths only)
+    pmc = None
+    pj = os.path.join(REPO, "profiles", PMC_LEVELS_FILE)
+    if os.path.exists(pj) and b == 16 and h == 256 and w == 256 and wh == 8 and n == 5:
+        with open(pj) as f:
+            pmc = json.load(f)
     hh, wd = h, w
     shapes = []
     for s in range(n):   # map of level s: merged (reflect-padded to the merge size), then padded to a multiple of the window
@@ -194,6 +203,10 @@ def level_rooflines(model, ir, vis, step_ms, iters=5):
                      "frac_hbm": round(blk_bytes / (us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
                      "frac_mfma": round(blk_flops / (us * 1e-6) / MFMA_PEAK_FLOPS, 4),
                      "frac_mfma_issued": round((blk_flops + 2 * lin_flops) / (us * 1e-6) / MFMA_PEAK_FLOPS, 4)}
+            if pmc and side == "encoder" and str(lvl) in pmc.get("levels", {}):
+                entry["pmc"] = {"source": f"profiles/{PMC_LEVELS_FILE} (build {pmc.get('commit', '?')}; rocprofv3 --pmc, one block of the level in a loop)",
+                                "kernels": {k: {f: v[f] for f in ("us_under_pmc", "mfma_busy", "valu_active", "lds_conflict") if f in v}
+                                            for k, v in pmc["levels"][str(lvl)].items() if "split_planes" not in k and "layernorm_vec" not in k}}
             if lvl == 0 and side == "encoder" and c == 24 and hid == 96 and wh == 8:
                 # DESIGN.md section 5 issue model of window24_kernel<96, 8>: per wave and window 1 308 VALU wave-instructions priced by issue
                 # class (tools/valu_rate_bench.hip) = 2.67 us and 124 MFMAs = 1.76 us, serialised on the wave's SIMD; 4 waves per window
