@@ -40,6 +40,8 @@ def parse():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=16, help="pairs per GPU (BASELINE configs 2/4)")
     ap.add_argument("--size", type=int, default=256)
+    ap.add_argument("--height", type=int, default=0, help="non-square inputs: height (default: --size)")
+    ap.add_argument("--width", type=int, default=0, help="non-square inputs: width (default: --size)")
     ap.add_argument("--config", default="win8")
     ap.add_argument("--precision", default="fast", choices=["fast", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
@@ -53,7 +55,7 @@ def parse():
     return ap.parse_args()
 
 
-def level0_block_roofline(model, batch, size, precision, iters=20):
+def level0_block_roofline(model, batch, size, precision, iters=20, height=0, width=0):
     """Time the dominant unit — the level-0 BasicBlock (window attention + MLP on the full-resolution
     C=out_dims[0] map, both streams) — alone, with HIP events on the launch stream, and price it against
     HBM.  Algorithmic bytes per launch (attention half-block, both streams, e=4):
@@ -66,7 +68,7 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     mh, mw = model.merging_size
     # the level-0 map as the model runs it: merged (reflect-padded to the merge size), then padded to a multiple of the window
     wh, ww = blk.window_size
-    h, w = -(-(-(-size // mh)) // wh) * wh, -(-(-(-size // mw)) // ww) * ww
+    h, w = -(-(-(-(height or size) // mh)) // wh) * wh, -(-(-(-(width or size) // mw)) // ww) * ww
     dev = torch.device("cuda", torch.cuda.current_device())
     g = torch.Generator(device="cpu").manual_seed(7)
     x = torch.randn(batch, h, w, c, generator=g).to(dev)
@@ -114,7 +116,7 @@ def level0_block_roofline(model, batch, size, precision, iters=20):
     # (PMC counters cannot be read in-process: this field is a constant of the named file, not a measurement of this run)
     traffic, traffic_source = None, None
     tj = os.path.join(REPO, "profiles", TRAFFIC_FILE)
-    if os.path.exists(tj) and batch == 16 and size == 256 and c == 24 and precision == "fast" and blk.window_size[0] == 8:
+    if os.path.exists(tj) and batch == 16 and size == 256 and not height and not width and c == 24 and precision == "fast" and blk.window_size[0] == 8:
         with open(tj) as f:
             rec = json.load(f)
         traffic = rec.get("hbm_bytes_per_launch")
@@ -270,6 +272,8 @@ def cpu_baseline(cfg, size, pairs, iters):
 def baseline_config_label(args, cfg, world):
     """Which BASELINE.json config (0-based index into `configs`) this run is, derived from the arguments."""
     w = cfg.window_size[0]
+    if args.height or args.width:
+        return "not a BASELINE config"
     if cfg.n_levels == 5 and w == 8 and args.size == 256 and args.batch == 16:
         return "BASELINE configs[3], 8 GPUs" if world == 8 else ("BASELINE configs[1]" if world == 1 else f"BASELINE configs[3] shard size on {world} GPUs")
     if cfg.n_levels == 5 and w == 8 and args.size == 512 and args.batch == 16 and world == 1:
@@ -321,7 +325,8 @@ def main():
         runner = ShardedFusion(model, world_size=world, rank=rank, use_graph=not args.no_graph)
 
     # synthetic IR / visible pairs, distinct per rank, resident in HBM before the timed region
-    ir, vis = synthetic_pair(args.batch, args.size, args.size, seed_ir=1 + 2 * rank, seed_vis=2 + 2 * rank)
+    hh, ww_ = args.height or args.size, args.width or args.size
+    ir, vis = synthetic_pair(args.batch, hh, ww_, seed_ir=1 + 2 * rank, seed_vis=2 + 2 * rank)
     ir, vis = torch.from_numpy(ir).to(dev), torch.from_numpy(vis).to(dev)
 
     for _ in range(max(args.warmup, 1)):
@@ -359,11 +364,11 @@ def main():
     if rank == 0:
         total_pairs = args.batch * world * args.steps
         line = {
-            "metric": f"fused image-pairs/sec at {args.size}x{args.size}, win={cfg.window_size[0]}", "value": round(total_pairs / elapsed, 2),
+            "metric": f"fused image-pairs/sec at {hh}x{ww_}, win={cfg.window_size[0]}", "value": round(total_pairs / elapsed, 2),
             "unit": "pairs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "bf16" if args.precision == "fast" else "f32", "data": "synthetic",
-            "config": {"workload": f"B={args.batch}/GPU {args.size}x{args.size} IR/visible pairs, win={cfg.window_size[0]}, "
+            "config": {"workload": f"B={args.batch}/GPU {hh}x{ww_} IR/visible pairs, win={cfg.window_size[0]}, "
                                    f"{cfg.n_levels}-level Swin-UNet fusion forward ({baseline_config_label(args, cfg, world)})",
                        "global_batch": args.batch * world, "precision_mode": args.precision,
                        "arithmetic": "linear layers split-bf16 (bf16x3) MFMA, QK^T and P.V fp16 MFMA (fp32 accumulate), everything else fp32"
@@ -377,7 +382,7 @@ def main():
             line["data"] = "synthetic; DRY RUN on CPU over gloo with a stub forward: the value measures nothing"
             line["config"]["collective"] = "gloo all_gather (stub forward)" if world > 1 else "none"
         else:
-            line["roofline"] = level0_block_roofline(model, args.batch, args.size, args.precision)
+            line["roofline"] = level0_block_roofline(model, args.batch, args.size, args.precision, height=args.height, width=args.width)
             if not args.no_levels and args.precision == "fast":
                 per_level = level_rooflines(model, ir, vis, elapsed / args.steps * 1e3)
                 if per_level:
