@@ -133,6 +133,24 @@ int swf_basic_block_fwd_packed(const swf_block_desc* desc, const void* packed,
                                const float* x_in, const float* y_in, float* x_out, float* y_out,
                                int32_t B, int32_t H, int32_t W, swf_stream_t stream);
 
+/* ---- training side, first stage: backward of one BasicBlock ------------------------------------------------
+ * What torch.autograd computes for a005_BasicBlock.py:127-145 inside the reference's training step (a016_train.py:150-196), in
+ * exact fp32.  The forward intermediates are recomputed from the block's inputs, so nothing has to be saved by the forward call.
+ * gx_out / gy_out: dL/d(block outputs); gx_in / gy_in: dL/d(block inputs) (written); gpx / gpy: where the parameter gradients go —
+ * the same fields as swf_block_stream_params, every non-NULL pointer is OVERWRITTEN with the gradient of that tensor (NULL = not
+ * wanted).  py / y_* / gpy NULL for a single-path block.  Sums over tokens run in a fixed order (no atomics): bit-reproducible. */
+typedef struct swf_linear_grad { float* weight; float* bias; } swf_linear_grad;
+typedef struct swf_norm_grad { float* gamma; float* beta; } swf_norm_grad;
+typedef struct swf_attn_grads { swf_linear_grad q, k, v, proj; float* bias_table; } swf_attn_grads;
+typedef struct swf_block_stream_grads {
+    swf_norm_grad ln1; swf_attn_grads attn; swf_norm_grad ln2; swf_linear_grad fc1, fc2;
+} swf_block_stream_grads;
+size_t swf_basic_block_bwd_workspace_bytes(const swf_block_desc* desc, int32_t B, int32_t H, int32_t W);
+int swf_basic_block_bwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
+                        const float* x_in, const float* y_in, const float* gx_out, const float* gy_out,
+                        float* gx_in, float* gy_in, const swf_block_stream_grads* gpx, const swf_block_stream_grads* gpy,
+                        int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
 /* SelfAndCrossBlockPair.forward (a012_SelfAndCrossBlockPair.py:70-78): four BasicBlocks in the
  * order self/normal, self/shifted, cross/normal, cross/shifted (a009:90-109).  `desc` gives the
  * shared dims; shift/cross flags inside it are ignored.  px[4], py[4]. */

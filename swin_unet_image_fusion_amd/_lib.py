@@ -82,6 +82,9 @@ SIGNATURES = {
     "swf_basic_block_packed_bytes": (_sz, [P(BlockDesc)]),
     "swf_basic_block_pack": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _sz, _vp]),
     "swf_basic_block_fwd_packed": (C.c_int, [P(BlockDesc), _vp, _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp]),
+    "swf_basic_block_bwd_workspace_bytes": (_sz, [P(BlockDesc), _i32, _i32, _i32]),
+    "swf_basic_block_bwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _vp, _vp,
+                                      P(BlockStreamParams), P(BlockStreamParams), _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_block_pair4_fwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_patch_merge_fwd": (C.c_int, [P(PatchParams), _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_merge_out_shape": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, P(_i32), P(_i32), P(_i32), P(_i32)]),

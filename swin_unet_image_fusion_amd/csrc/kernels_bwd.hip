@@ -1,0 +1,503 @@
+// Backward of one BasicBlock (a005_BasicBlock.py:127-145 under torch.autograd, as the reference's training loop runs it:
+// a016_train.py:150-196) in exact fp32 — SURVEY.md section 8(f) rank 4, first stage: the block, not yet the patch layers / head / loss.
+//
+//   x1 = x + proj(attention(q, k, v)),  q = Wq LN1(x) + bq,  k / v from LN1 of the own (self) or the other (cross) stream
+//   x2 = x1 + W2 ELU(W1 LN2(x1) + b1) + b2
+//
+// The backward RECOMPUTES the forward intermediates from the block's inputs with the exact-tier forward kernels (kernels_generic.hip)
+// and then walks the graph in reverse with the kernels of this file:
+//   bwd_dx_kernel        dX (+)= dY . W                      (the input gradient of a linear layer; LDS-tiled fp32 FMA)
+//   bwd_dw_kernel        dW  = dY^T . X, token chunks -> partial sums, reduced in fixed order (bit-reproducible, no atomics)
+//   bwd_colsum_kernel    db  = column sums of dY, same chunking
+//   ln_bwd_kernel        LayerNorm backward per token (+ the residual branch's gradient) and per-wave partial d gamma / d beta
+//   elu_bwd_kernel       du = dh . (h > 0 ? 1 : h + 1)     (ELU'(u) from the saved output: exp(u) = h + 1 for u <= 0)
+//   attn_bwd_kernel      per (window, head): recomputes the scores (bias, shift mask assigned as -1e10: a001:310), softmax statistics and
+//                        dS = P . (dP - rowsum(dP . P)); thread = query for dQ, thread = key for dK / dV, thread = table entry for the
+//                        relative-position bias gradient — every sum in a fixed order
+//   reduce_rows_kernel   out[i] = sum over partial rows in index order
+// Everything here is test-covered against torch.autograd of the CPU oracle (tests/test_gpu_backward.py).  It is the plain,
+// correct-first tier: no MFMA, no fusion.
+#include "kernels_bwd.h"
+
+#include <algorithm>
+
+#include "kernels_generic.h"
+
+namespace swf {
+namespace {
+
+constexpr int kChunk = 2048;   // tokens per partial sum of bwd_dw / bwd_colsum
+
+// out[M][K] (+)= dY[M][N] . W[N][K]
+__global__ __launch_bounds__(256) void bwd_dx_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ out,
+                                                      int M, int N, int K, int accumulate) {
+    __shared__ float As[64][17];
+    __shared__ float Bs[16][65];
+    const int m0 = blockIdx.y * 64, k0 = blockIdx.x * 64;
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    float acc[4][4] = {};
+    for (int n0 = 0; n0 < N; n0 += 16) {
+        for (int e = tid; e < 64 * 16; e += 256) {
+            const int r = e >> 4, c = e & 15;
+            As[r][c] = (m0 + r < M && n0 + c < N) ? dY[(int64_t)(m0 + r) * N + n0 + c] : 0.f;
+        }
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            Bs[r][c] = (n0 + r < N && k0 + c < K) ? W[(int64_t)(n0 + r) * K + k0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int n = 0; n < 16; ++n) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[4 * ty + i][n]; b[i] = Bs[n][4 * tx + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = m0 + 4 * ty + i, k = k0 + 4 * tx + j;
+            if (m < M && k < K) {
+                float* o = out + (int64_t)m * K + k;
+                *o = accumulate ? *o + acc[i][j] : acc[i][j];
+            }
+        }
+}
+
+// partial[chunk][N][K] = sum over the chunk's tokens of dY[m][n] X[m][k]
+__global__ __launch_bounds__(256) void bwd_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ partial,
+                                                      int M, int N, int K) {
+    __shared__ float As[16][65];
+    __shared__ float Bs[16][65];
+    const int n0 = blockIdx.y * 64, k0 = blockIdx.x * 64, chunk = blockIdx.z;
+    const int mlo = chunk * kChunk, mhi = min(M, mlo + kChunk);
+    const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+    float acc[4][4] = {};
+    for (int m0 = mlo; m0 < mhi; m0 += 16) {
+        for (int e = tid; e < 16 * 64; e += 256) {
+            const int r = e >> 6, c = e & 63;
+            const bool live = m0 + r < mhi;
+            As[r][c] = (live && n0 + c < N) ? dY[(int64_t)(m0 + r) * N + n0 + c] : 0.f;
+            Bs[r][c] = (live && k0 + c < K) ? X[(int64_t)(m0 + r) * K + k0 + c] : 0.f;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int m = 0; m < 16; ++m) {
+            float a[4], b[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) { a[i] = As[m][4 * ty + i]; b[i] = Bs[m][4 * tx + i]; }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(a[i], b[j], acc[i][j]);
+        }
+        __syncthreads();
+    }
+    float* p = partial + (int64_t)chunk * N * K;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + 4 * ty + i, k = k0 + 4 * tx + j;
+            if (n < N && k < K) p[(int64_t)n * K + k] = acc[i][j];
+        }
+}
+
+// partial[chunk][N] = column sums of dY over the chunk's tokens
+__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float* __restrict__ dY, float* __restrict__ partial, int M, int N) {
+    const int chunk = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const int mlo = chunk * kChunk, mhi = min(M, mlo + kChunk);
+    float s = 0.f;
+    for (int m = mlo; m < mhi; ++m) s += dY[(int64_t)m * N + n];
+    partial[(int64_t)chunk * N + n] = s;
+}
+
+// out[i] = sum_r partial[r][i], r in index order
+__global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t count, int rows) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * count + i];
+    out[i] = s;
+}
+
+__global__ __launch_bounds__(256) void elu_bwd_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t count) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    const float hv = h[i];
+    dh[i] *= hv > 0.f ? 1.0f : hv + 1.0f;
+}
+
+// LayerNorm backward (eps 1e-5, biased variance; a004:54-72 / nn.LayerNorm):  with xhat = (x - mean) rstd, g = dy gamma:
+//   dx = rstd (g - mean(g) - xhat mean(g xhat)) (+ dres);   d gamma = sum_tokens dy xhat;   d beta = sum_tokens dy.
+// One wave per token row, eight rows per wave; lane l owns channels l, l + 64, ...  The wave's partial d gamma / d beta rows go to
+// pgb[(block * 4 + wave)][2][C]; reduce_rows_kernel sums them in index order.
+constexpr int kLnRows = 8, kLnMaxCh = 16;   // C <= 1024
+__global__ __launch_bounds__(256) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gamma, const float* __restrict__ dy,
+                                                      const float* __restrict__ dres, float* __restrict__ dx, float* __restrict__ pgb,
+                                                      int64_t M, int C) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t row0 = ((int64_t)blockIdx.x * 4 + wave) * kLnRows;
+    float dg[kLnMaxCh], db[kLnMaxCh];
+#pragma unroll
+    for (int i = 0; i < kLnMaxCh; ++i) { dg[i] = 0.f; db[i] = 0.f; }
+    for (int rr = 0; rr < kLnRows; ++rr) {
+        const int64_t m = row0 + rr;
+        if (m >= M) break;   // wave-uniform
+        const float* xr = x + m * C;
+        const float* dyr = dy + m * C;
+        float s = 0.f;
+        for (int c = lane; c < C; c += 64) s += xr[c];
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        const float mean = s / (float)C;
+        float q = 0.f;
+        for (int c = lane; c < C; c += 64) { const float d = xr[c] - mean; q += d * d; }
+        for (int o = 32; o > 0; o >>= 1) q += __shfl_xor(q, o);
+        const float rstd = 1.0f / sqrtf(q / (float)C + 1e-5f);
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int i = 0; i < kLnMaxCh; ++i) {
+            const int c = lane + 64 * i;
+            if (c < C) {
+                const float xh = (xr[c] - mean) * rstd, d = dyr[c], g = d * gamma[c];
+                sg += g; sgx += g * xh;
+                dg[i] += d * xh; db[i] += d;
+            }
+        }
+        for (int o = 32; o > 0; o >>= 1) { sg += __shfl_xor(sg, o); sgx += __shfl_xor(sgx, o); }
+        const float mg = sg / (float)C, mgx = sgx / (float)C;
+        for (int c = lane; c < C; c += 64) {
+            const float xh = (xr[c] - mean) * rstd, g = dyr[c] * gamma[c];
+            float v = rstd * (g - mg - xh * mgx);
+            if (dres) v += dres[m * C + c];
+            dx[m * C + c] = v;
+        }
+    }
+    float* p = pgb + ((int64_t)blockIdx.x * 4 + wave) * 2 * C;
+#pragma unroll
+    for (int i = 0; i < kLnMaxCh; ++i) {
+        const int c = lane + 64 * i;
+        if (c < C) { p[c] = dg[i]; p[C + c] = db[i]; }
+    }
+}
+
+// ---- attention backward ------------------------------------------------------------------------------------------------------------
+// One workgroup = one (window, head); Q, K, V, dO rows of the head in LDS (zero-padded to DMAX).  Scores exactly as attn_core_kernel.
+struct AttnBwdProb {
+    const float* Q; const float* K; const float* V; const float* dO;   // [tokens][heads*d], row stride ld
+    float* dQ; float* dK; float* dV;
+    const float* bias_table;
+    float* dtable_partial;   // [windows * heads][table entries]
+};
+struct AttnBwdBatch { AttnBwdProb p[2]; };
+
+template <int DMAX>
+__global__ void attn_bwd_kernel(AttnBwdBatch batch, int ld, int B, int H, int W, int wh, int ww, int heads, int d, int shift, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AttnBwdProb pr = batch.p[blockIdx.z];
+    const int t = wh * ww;
+    float* Qs = smem;
+    float* Ks = Qs + t * DMAX;
+    float* Vs = Ks + t * DMAX;
+    float* Gs = Vs + t * DMAX;           // dO
+    float* tab = Gs + t * DMAX;
+    const int tw = 2 * ww - 1, tsz = (2 * wh - 1) * tw;
+    float* mrow = tab + tsz;             // per query: max, 1 / sum, D = sum_j p_ij dP_ij
+    float* linv = mrow + t;
+    float* Drow = linv + t;
+    const int nwx = W / ww, nwy = H / wh;
+    const int win = blockIdx.x, head = blockIdx.y;
+    const int b = win / (nwx * nwy), wrem = win % (nwx * nwy);
+    const int wy = wrem / nwx, wx = wrem % nwx;
+    const int sh = shift ? wh / 2 : 0, sw = shift ? ww / 2 : 0;
+    const int tid = threadIdx.x;
+    auto token_of = [&](int j) -> int64_t {
+        const int sy = wy * wh + j / ww, sx = wx * ww + j % ww;
+        const int oy = (sy + sh) % H, ox = (sx + sw) % W;
+        return ((int64_t)b * H + oy) * W + ox;
+    };
+    auto region_of = [&](int j) {
+        const int sy = wy * wh + j / ww, sx = wx * ww + j % ww;
+        return ((sy >= H - wh) + (sy >= H - wh / 2)) * 3 + ((sx >= W - ww) + (sx >= W - ww / 2));
+    };
+    for (int i = tid; i < tsz; i += blockDim.x) tab[i] = pr.bias_table[i];
+    for (int e = tid; e < t * DMAX; e += blockDim.x) {
+        const int j = e / DMAX, c = e % DMAX;
+        float qv = 0.f, kv = 0.f, vv = 0.f, gv = 0.f;
+        if (c < d) {
+            const int64_t o = token_of(j) * ld + head * d + c;
+            qv = pr.Q[o]; kv = pr.K[o]; vv = pr.V[o]; gv = pr.dO[o];
+        }
+        Qs[e] = qv; Ks[e] = kv; Vs[e] = vv; Gs[e] = gv;
+    }
+    __syncthreads();
+    auto score = [&](int i, int j) -> float {   // exactly attn_core_kernel's score(i, j)
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) dot = fmaf(Qs[i * DMAX + c], Ks[j * DMAX + c], dot);
+        float s = dot * scale + tab[(j / ww - i / ww + wh - 1) * tw + (j % ww - i % ww + ww - 1)];
+        if (shift && region_of(j) != region_of(i)) s = -1e10f;
+        return s;
+    };
+    auto dP = [&](int i, int j) -> float {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) dot = fmaf(Gs[i * DMAX + c], Vs[j * DMAX + c], dot);
+        return dot;
+    };
+    // ---- pass 1, thread = query i: softmax statistics, D_i, dQ_i ----
+    if (tid < t) {
+        const int i = tid;
+        float mx = -INFINITY;
+        for (int j = 0; j < t; ++j) mx = fmaxf(mx, score(i, j));
+        float l = 0.f;
+        for (int j = 0; j < t; ++j) l += expf(score(i, j) - mx);
+        const float inv = 1.0f / l;
+        float D = 0.f;
+        for (int j = 0; j < t; ++j) D = fmaf(expf(score(i, j) - mx) * inv, dP(i, j), D);
+        mrow[i] = mx; linv[i] = inv; Drow[i] = D;
+        float dq[DMAX];
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) dq[c] = 0.f;
+        for (int j = 0; j < t; ++j) {
+            const float s = score(i, j);
+            // the masked scores were ASSIGNED the constant -1e10 (a001:310): no gradient flows through them (their p is 0 anyway)
+            const float p = expf(s - mx) * inv, ds = p * (dP(i, j) - D);
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c) dq[c] = fmaf(ds, Ks[j * DMAX + c], dq[c]);
+        }
+        const int64_t o = token_of(i) * ld + head * d;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c)
+            if (c < d) pr.dQ[o + c] = dq[c] * scale;
+    }
+    __syncthreads();
+    // ---- pass 2, thread = key j: dK_j, dV_j ----
+    if (tid < t) {
+        const int j = tid;
+        float dk[DMAX], dv[DMAX];
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) { dk[c] = 0.f; dv[c] = 0.f; }
+        const int rj = region_of(j);
+        for (int i = 0; i < t; ++i) {
+            const float s = score(i, j);
+            const float p = expf(s - mrow[i]) * linv[i];
+            const bool masked = shift && rj != region_of(i);
+            const float ds = masked ? 0.f : p * (dP(i, j) - Drow[i]);
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c) {
+                dk[c] = fmaf(ds, Qs[i * DMAX + c], dk[c]);
+                dv[c] = fmaf(p, Gs[i * DMAX + c], dv[c]);
+            }
+        }
+        const int64_t o = token_of(j) * ld + head * d;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c)
+            if (c < d) { pr.dK[o + c] = dk[c] * scale; pr.dV[o + c] = dv[c]; }
+    }
+    // ---- pass 3, thread = table entry: d table[(dy, dx)] = sum over the (query, key) pairs at that offset of dS (unmasked pairs only) ----
+    float* dt = pr.dtable_partial + ((int64_t)win * heads + head) * tsz;
+    for (int e = tid; e < tsz; e += blockDim.x) {
+        const int dy = e / tw - (wh - 1), dx = e % tw - (ww - 1);   // key - query
+        float acc = 0.f;
+        for (int i = 0; i < t; ++i) {
+            const int jy = i / ww + dy, jx = i % ww + dx;
+            if (jy < 0 || jy >= wh || jx < 0 || jx >= ww) continue;
+            const int j = jy * ww + jx;
+            if (shift && region_of(j) != region_of(i)) continue;
+            const float p = expf(score(i, j) - mrow[i]) * linv[i];
+            acc += p * (dP(i, j) - Drow[i]);
+        }
+        dt[e] = acc;
+    }
+}
+
+template <int DMAX>
+int launch_attn_bwd_t(const AttnBwdBatch& batch, int nprob, int ld, int B, int H, int W, int wh, int ww, int heads, int d, int shift, hipStream_t stream) {
+    const int t = wh * ww, tsz = (2 * wh - 1) * (2 * ww - 1);
+    const size_t lds = ((size_t)4 * t * DMAX + tsz + 3 * t) * sizeof(float);
+    if (lds > 160 * 1024) return fail(SWF_ERR_UNSUPPORTED, "attention backward tile (t=%d, d=%d) needs %zu B of LDS", t, d, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<DMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(attn_bwd): %s", hipGetErrorString(e));
+    }
+    const int threads = cdiv(t, 64) * 64;
+    if (threads > 1024) return fail(SWF_ERR_UNSUPPORTED, "attention backward: window of %d tokens > 1024", t);
+    dim3 grid(B * (H / wh) * (W / ww), heads, nprob);
+    hipLaunchKernelGGL(attn_bwd_kernel<DMAX>, grid, dim3(threads), lds, stream, batch, ld, B, H, W, wh, ww, heads, d, shift, 1.0f / sqrtf((float)d));
+    return check_launch("attn_bwd");
+}
+
+int launch_attn_bwd(const AttnBwdBatch& batch, int nprob, int ld, int B, int H, int W, int wh, int ww, int heads, int d, int shift, hipStream_t stream) {
+#define SWF_AB(D) return launch_attn_bwd_t<D>(batch, nprob, ld, B, H, W, wh, ww, heads, d, shift, stream)
+    if (d <= 4) SWF_AB(4);
+    if (d <= 8) SWF_AB(8);
+    if (d <= 16) SWF_AB(16);
+    if (d <= 32) SWF_AB(32);
+    if (d <= 64) SWF_AB(64);
+#undef SWF_AB
+    return fail(SWF_ERR_UNSUPPORTED, "attention backward: head_dim %d > 64", d);
+}
+
+// ---- host helpers ----------------------------------------------------------------------------------------------------------------------
+int dx(const float* dY, const float* W, float* out, int64_t M, int N, int K, int accumulate, hipStream_t st) {
+    dim3 grid(cdiv(K, 64), (unsigned)cdiv64(M, 64));
+    hipLaunchKernelGGL(bwd_dx_kernel, grid, dim3(256), 0, st, dY, W, out, (int)M, N, K, accumulate);
+    return check_launch("bwd_dx");
+}
+int chunks_of(int64_t M) { return (int)cdiv64(M, kChunk); }
+// dW [N][K] (and db [N] when asked) of a linear layer y = x W^T + b from dY [M][N] and X [M][K]; scratch: chunks * N * (K + 1) floats
+int dw(const float* dY, const float* X, float* dW, float* db, int64_t M, int N, int K, float* scratch, hipStream_t st) {
+    const int ch = chunks_of(M);
+    if (dW) {
+        hipLaunchKernelGGL(bwd_dw_kernel, dim3(cdiv(K, 64), cdiv(N, 64), ch), dim3(256), 0, st, dY, X, scratch, (int)M, N, K);
+        SWF_TRY(check_launch("bwd_dw"));
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv64((int64_t)N * K, 256)), dim3(256), 0, st, scratch, dW, (int64_t)N * K, ch);
+        SWF_TRY(check_launch("bwd_dw reduce"));
+    }
+    if (db) {
+        float* ps = scratch + (int64_t)ch * N * K;
+        hipLaunchKernelGGL(bwd_colsum_kernel, dim3(cdiv(N, 256), ch), dim3(256), 0, st, dY, ps, (int)M, N);
+        SWF_TRY(check_launch("bwd_colsum"));
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, ps, db, (int64_t)N, ch);
+        SWF_TRY(check_launch("bwd_colsum reduce"));
+    }
+    return SWF_OK;
+}
+int ln_blocks(int64_t M) { return (int)cdiv64(M, 4 * kLnRows); }
+// dx = dres + LayerNorm backward of dy; d gamma / d beta (either may be NULL); scratch: ln_blocks * 4 * 2 * C + 2 * C floats
+int ln_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dxo, float* dgamma, float* dbeta, int64_t M, int C,
+           float* scratch, hipStream_t st) {
+    if (C > 64 * kLnMaxCh) return fail(SWF_ERR_UNSUPPORTED, "LayerNorm backward: C = %d > %d", C, 64 * kLnMaxCh);
+    const int nb = ln_blocks(M);
+    hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dxo, scratch, M, C);
+    SWF_TRY(check_launch("ln_bwd"));
+    if (dgamma || dbeta) {
+        float* red = scratch + (int64_t)nb * 4 * 2 * C;
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, scratch, red, (int64_t)2 * C, nb * 4);
+        SWF_TRY(check_launch("ln_bwd reduce"));
+        if (dgamma && hipMemcpyAsync(dgamma, red, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SWF_ERR_HIP, "ln_bwd: copy failed");
+        if (dbeta && hipMemcpyAsync(dbeta, red + C, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SWF_ERR_HIP, "ln_bwd: copy failed");
+    }
+    return SWF_OK;
+}
+
+}  // namespace
+
+size_t basic_block_bwd_ws(const swf_block_desc& d, int nstream, int B, int H, int W) {
+    const int64_t N = (int64_t)B * H * W, C = d.attn.channels, HD = (int64_t)d.attn.heads * d.attn.head_dim, hid = d.hidden;
+    const int64_t nwin = (int64_t)B * (H / d.attn.win_h) * (W / d.attn.win_w), tsz = (int64_t)(2 * d.attn.win_h - 1) * (2 * d.attn.win_w - 1);
+    const int64_t mx = std::max(std::max(C, HD), hid);
+    size_t t = 0;
+    for (int s = 0; s < nstream; ++s)
+        t += carve_bytes({N * C, N * HD, N * HD, N * HD, N * HD, N * C, N * C, N * hid,      // xn, q, k, v, o, x1, xn2, h
+                          N * hid, N * C, N * C, N * HD, N * HD, N * HD, N * HD, N * C,      // dh, dxn2, gx1, do, dq, dk, dv, dxn
+                          nwin * d.attn.heads * tsz});
+    t += carve_bytes({(int64_t)chunks_of(N) * mx * (mx + 1) + (int64_t)ln_blocks(N) * 8 * C + 2 * C + 64});
+    return t;
+}
+
+int basic_block_bwd(const swf_block_desc& d, const swf_block_stream_params* px, const swf_block_stream_params* py, const float* x_in,
+                    const float* y_in, const float* gx_out, const float* gy_out, float* gx_in, float* gy_in, const swf_block_stream_grads* gx,
+                    const swf_block_stream_grads* gy, int B, int H, int W, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    const int nstream = py ? 2 : 1;
+    const int64_t N = (int64_t)B * H * W;
+    const int C = d.attn.channels, HD = d.attn.heads * d.attn.head_dim, hid = d.hidden;
+    const bool cross = d.cross && nstream == 2;
+    const int wh = d.attn.win_h, ww = d.attn.win_w, tsz = (2 * wh - 1) * (2 * ww - 1);
+    const int64_t nwin = (int64_t)B * (H / wh) * (W / ww);
+    if (N > INT32_MAX / std::max(std::max(C, HD), hid)) return fail(SWF_ERR_UNSUPPORTED, "basic_block_bwd: token count");
+    Carver ws(workspace, workspace_bytes);
+    struct S { float *xn, *q, *k, *v, *o, *x1, *xn2, *h, *dh, *dxn2, *gx1, *dO, *dq, *dk, *dv, *dxn, *dtab; } b[2];
+    for (int s = 0; s < nstream; ++s) {
+        b[s].xn = ws.floats(N * C); b[s].q = ws.floats(N * HD); b[s].k = ws.floats(N * HD); b[s].v = ws.floats(N * HD); b[s].o = ws.floats(N * HD);
+        b[s].x1 = ws.floats(N * C); b[s].xn2 = ws.floats(N * C); b[s].h = ws.floats(N * hid);
+        b[s].dh = ws.floats(N * hid); b[s].dxn2 = ws.floats(N * C); b[s].gx1 = ws.floats(N * C); b[s].dO = ws.floats(N * HD);
+        b[s].dq = ws.floats(N * HD); b[s].dk = ws.floats(N * HD); b[s].dv = ws.floats(N * HD); b[s].dxn = ws.floats(N * C);
+        b[s].dtab = ws.floats(nwin * d.attn.heads * tsz);
+    }
+    const int64_t mx = std::max(std::max(C, HD), hid);
+    float* scratch = ws.floats((int64_t)chunks_of(N) * mx * (mx + 1) + (int64_t)ln_blocks(N) * 8 * C + 2 * C + 64);
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "basic_block_bwd workspace too small (need %zu B)", ws.used);
+    const swf_block_stream_params* pp[2] = {px, py};
+    const swf_block_stream_grads* gp[2] = {gx, gy};
+    const float* xin[2] = {x_in, y_in};
+    const float* gout[2] = {gx_out, gy_out};
+    float* gin[2] = {gx_in, gy_in};
+
+    // ---- recompute the forward intermediates (exact tier) ----
+    {
+        LnBatch l1{};
+        for (int s = 0; s < nstream; ++s) l1.p[s] = LnProb{xin[s], b[s].xn, pp[s]->ln1.gamma, pp[s]->ln1.beta};
+        SWF_TRY(launch_layernorm(l1, nstream, N, C, 0, st));
+        GemmBatch gq{};
+        for (int s = 0; s < nstream; ++s) {
+            const int kvs = cross ? 1 - s : s;
+            gq.p[3 * s] = GemmProb{b[s].xn, pp[s]->attn.q.weight, pp[s]->attn.q.bias, nullptr, b[s].q};
+            gq.p[3 * s + 1] = GemmProb{b[kvs].xn, pp[s]->attn.k.weight, pp[s]->attn.k.bias, nullptr, b[s].k};
+            gq.p[3 * s + 2] = GemmProb{b[kvs].xn, pp[s]->attn.v.weight, pp[s]->attn.v.bias, nullptr, b[s].v};
+        }
+        SWF_TRY(launch_gemm_f32(gq, 3 * nstream, (int)N, HD, C, C, HD, 0, st));
+        AttnCoreBatch ab{};
+        for (int s = 0; s < nstream; ++s) ab.p[s] = AttnCoreProb{b[s].q, b[s].k, b[s].v, b[s].o, pp[s]->attn.bias_table};
+        SWF_TRY(launch_attn_core(ab, nstream, HD, HD, HD, HD, B, H, W, wh, ww, d.attn.heads, d.attn.head_dim, d.attn.shift, st));
+        GemmBatch gpj{};
+        for (int s = 0; s < nstream; ++s) gpj.p[s] = GemmProb{b[s].o, pp[s]->attn.proj.weight, pp[s]->attn.proj.bias, xin[s], b[s].x1};
+        SWF_TRY(launch_gemm_f32(gpj, nstream, (int)N, C, HD, HD, C, 0, st));
+        LnBatch l2{};
+        for (int s = 0; s < nstream; ++s) l2.p[s] = LnProb{b[s].x1, b[s].xn2, pp[s]->ln2.gamma, pp[s]->ln2.beta};
+        SWF_TRY(launch_layernorm(l2, nstream, N, C, 0, st));
+        GemmBatch g1{};
+        for (int s = 0; s < nstream; ++s) g1.p[s] = GemmProb{b[s].xn2, pp[s]->fc1.weight, pp[s]->fc1.bias, nullptr, b[s].h};
+        SWF_TRY(launch_gemm_f32(g1, nstream, (int)N, hid, C, C, hid, 1, st));
+    }
+    auto G = [&](int s) -> const swf_block_stream_grads& { static const swf_block_stream_grads none{}; return gp[s] ? *gp[s] : none; };
+    // ---- MLP half, reverse ----
+    for (int s = 0; s < nstream; ++s) {
+        SWF_TRY(dx(gout[s], pp[s]->fc2.weight, b[s].dh, N, C, hid, 0, st));                                   // dh = g2 . W2
+        SWF_TRY(dw(gout[s], b[s].h, G(s).fc2.weight, G(s).fc2.bias, N, C, hid, scratch, st));                 // dW2, db2
+        hipLaunchKernelGGL(elu_bwd_kernel, dim3((unsigned)cdiv64(N * hid, 256)), dim3(256), 0, st, b[s].dh, b[s].h, N * hid);
+        SWF_TRY(check_launch("elu_bwd"));
+        SWF_TRY(dx(b[s].dh, pp[s]->fc1.weight, b[s].dxn2, N, hid, C, 0, st));                                 // dxn2 = du . W1
+        SWF_TRY(dw(b[s].dh, b[s].xn2, G(s).fc1.weight, G(s).fc1.bias, N, hid, C, scratch, st));               // dW1, db1
+        SWF_TRY(ln_bwd(b[s].x1, pp[s]->ln2.gamma, b[s].dxn2, gout[s], b[s].gx1, G(s).ln2.gamma, G(s).ln2.beta, N, C, scratch, st));
+        SWF_TRY(dx(b[s].gx1, pp[s]->attn.proj.weight, b[s].dO, N, C, HD, 0, st));                              // dO = gx1 . Wp
+        SWF_TRY(dw(b[s].gx1, b[s].o, G(s).attn.proj.weight, G(s).attn.proj.bias, N, C, HD, scratch, st));
+    }
+    // ---- attention core, reverse ----
+    {
+        AttnBwdBatch ab{};
+        for (int s = 0; s < nstream; ++s)
+            ab.p[s] = AttnBwdProb{b[s].q, b[s].k, b[s].v, b[s].dO, b[s].dq, b[s].dk, b[s].dv, pp[s]->attn.bias_table, b[s].dtab};
+        SWF_TRY(launch_attn_bwd(ab, nstream, HD, B, H, W, wh, ww, d.attn.heads, d.attn.head_dim, d.attn.shift, st));
+        for (int s = 0; s < nstream; ++s)
+            if (G(s).attn.bias_table) {
+                hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(tsz, 256)), dim3(256), 0, st, b[s].dtab, G(s).attn.bias_table, (int64_t)tsz,
+                                   (int)(nwin * d.attn.heads));
+                SWF_TRY(check_launch("dtable reduce"));
+            }
+    }
+    // ---- Q / K / V projections, reverse: stream s's K and V read the normalised tokens of stream kvs (a002:67-82) ----
+    for (int s = 0; s < nstream; ++s) SWF_TRY(dx(b[s].dq, pp[s]->attn.q.weight, b[s].dxn, N, HD, C, 0, st));   // initialises dxn[s]
+    for (int s = 0; s < nstream; ++s) {
+        const int kvs = cross ? 1 - s : s;
+        SWF_TRY(dx(b[s].dk, pp[s]->attn.k.weight, b[kvs].dxn, N, HD, C, 1, st));
+        SWF_TRY(dx(b[s].dv, pp[s]->attn.v.weight, b[kvs].dxn, N, HD, C, 1, st));
+        SWF_TRY(dw(b[s].dq, b[s].xn, G(s).attn.q.weight, G(s).attn.q.bias, N, HD, C, scratch, st));
+        SWF_TRY(dw(b[s].dk, b[kvs].xn, G(s).attn.k.weight, G(s).attn.k.bias, N, HD, C, scratch, st));
+        SWF_TRY(dw(b[s].dv, b[kvs].xn, G(s).attn.v.weight, G(s).attn.v.bias, N, HD, C, scratch, st));
+    }
+    // ---- LN1, reverse: the input gradient = gx1 (residual branch) + LayerNorm backward of dxn ----
+    for (int s = 0; s < nstream; ++s)
+        SWF_TRY(ln_bwd(xin[s], pp[s]->ln1.gamma, b[s].dxn, b[s].gx1, gin[s], G(s).ln1.gamma, G(s).ln1.beta, N, C, scratch, st));
+    return SWF_OK;
+}
+
+}  // namespace swf

@@ -10,6 +10,7 @@
 #include "kernels_generic.h"
 #include <cstdlib>
 #include "kernels_window.h"
+#include "kernels_bwd.h"
 #include "kernels_win24.h"
 #include "kernels_win48.h"
 #include "kernels_win96.h"
@@ -1174,6 +1175,20 @@ int swf_basic_block_fwd_packed(const swf_block_desc* desc, const void* packed, c
     if (!window_block_supported(*desc, B, H, W)) return fail(SWF_ERR_UNSUPPORTED, "no fused kernel for this block shape");
     const size_t pb = window_block_packed_bytes(*desc);
     return launch_window_block(*desc, packed, static_cast<const char*>(packed) + pb, x_in, y_in, x_out, y_out, B, H, W, as_stream(stream));
+}
+
+size_t swf_basic_block_bwd_workspace_bytes(const swf_block_desc* desc, int32_t B, int32_t H, int32_t W) {
+    if (!desc || B <= 0 || H <= 0 || W <= 0) return 0;
+    return basic_block_bwd_ws(*desc, 2, B, H, W);
+}
+
+int swf_basic_block_bwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py, const float* x_in,
+                        const float* y_in, const float* gx_out, const float* gy_out, float* gx_in, float* gy_in, const swf_block_stream_grads* gpx,
+                        const swf_block_stream_grads* gpy, int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes,
+                        swf_stream_t stream) {
+    SWF_TRY(check_block(desc, px, py, x_in, y_in, gx_in, gy_in, B, H, W, true, true));
+    if (!gx_out || (py && !gy_out)) return fail(SWF_ERR_NULL, "basic_block_bwd: NULL output gradient");
+    return basic_block_bwd(*desc, px, py, x_in, y_in, gx_out, gy_out, gx_in, gy_in, gpx, gpy, B, H, W, workspace, workspace_bytes, as_stream(stream));
 }
 
 int swf_block_pair4_fwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,

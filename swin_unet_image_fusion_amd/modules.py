@@ -352,6 +352,30 @@ class AddAndLayerNormWithOtherModule(_FwdAlias, nn.Module):
 # ----------------------------------------------------------------------------------------------
 # a005 / a009 / a012: blocks
 # ----------------------------------------------------------------------------------------------
+class _BasicBlockFunction(torch.autograd.Function):
+    """BasicBlock under torch.autograd: forward = the library's forward, backward = swf_basic_block_bwd (kernels_bwd.hip)."""
+
+    @staticmethod
+    def forward(ctx, block, dual, x, y, *params):
+        ctx.block, ctx.dual = block, dual
+        ctx.save_for_backward(x, y) if dual else ctx.save_for_backward(x)
+        ctx.nparams = len(params)
+        with torch.no_grad():
+            ox, oy = block._forward_nograd(x.detach(), y.detach() if dual else None, dual)
+        return (ox, oy) if dual else (ox,)
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        block, dual = ctx.block, ctx.dual
+        saved = ctx.saved_tensors
+        x, y = saved[0], (saved[1] if dual else None)
+        with torch.no_grad():
+            gx, gy, bufs = block._backward(x, y, gouts[0], gouts[1] if dual else None, dual)
+        streams = ("x", "y") if dual else ("x",)
+        pg = [g for s in streams for g in bufs[s]]
+        return (None, None, gx, gy, *pg)
+
+
 class BasicBlock(_FwdAlias, nn.Module):
     """a005_BasicBlock.BasicBlock (ctor a005:11-28, forward a005:127-145)."""
 
@@ -403,10 +427,88 @@ class BasicBlock(_FwdAlias, nn.Module):
         p.fc1, p.fc2 = _lin(getattr(self.auto_path_mlp, f"mlp_{s}_1")), _lin(getattr(self.auto_path_mlp, f"mlp_{s}_2"))
         return p
 
+    # ---- training side (first stage): the block under torch.autograd --------------------------------------------
+    _GRAD_FIELDS = ("ln1.weight", "ln1.bias", "q.weight", "q.bias", "k.weight", "k.bias", "v.weight", "v.bias", "proj.weight",
+                    "proj.bias", "table", "ln2.weight", "ln2.bias", "fc1.weight", "fc1.bias", "fc2.weight", "fc2.bias")
+
+    def _grad_tensors(self, s: str) -> List[Optional[Tensor]]:
+        """The stream's parameter tensors in the order of _GRAD_FIELDS (None where a layer has no bias)."""
+        idx = "1" if s == "x" else "2"
+        wa = getattr(self.auto_path_win_att, f"window_attention_{s}")
+        ln1, ln2 = getattr(self.stage_1, f"norm_layer_{idx}"), getattr(self.stage_2, f"norm_layer_{idx}")
+        f1, f2 = getattr(self.auto_path_mlp, f"mlp_{s}_1"), getattr(self.auto_path_mlp, f"mlp_{s}_2")
+        return [ln1.weight, ln1.bias, wa.q_for_heads.weight, wa.q_for_heads.bias, wa.k_for_heads.weight, wa.k_for_heads.bias,
+                wa.v_for_heads.weight, wa.v_for_heads.bias, wa.linear_projection.weight, wa.linear_projection.bias,
+                wa.relative_position_bias_table, ln2.weight, ln2.bias, f1.weight, f1.bias, f2.weight, f2.bias]
+
+    @staticmethod
+    def _grads_struct(bufs: List[Optional[Tensor]]) -> L.BlockStreamParams:
+        """swf_block_stream_grads over freshly allocated gradient buffers (same field order as swf_block_stream_params)."""
+        g = L.BlockStreamParams()
+        ptr = lambda t: None if t is None else t.data_ptr()
+        g.ln1 = L.Norm(ptr(bufs[0]), ptr(bufs[1]))
+        g.attn = L.AttnParams(L.Linear(ptr(bufs[2]), ptr(bufs[3])), L.Linear(ptr(bufs[4]), ptr(bufs[5])), L.Linear(ptr(bufs[6]), ptr(bufs[7])),
+                              L.Linear(ptr(bufs[8]), ptr(bufs[9])), ptr(bufs[10]))
+        g.ln2 = L.Norm(ptr(bufs[11]), ptr(bufs[12]))
+        g.fc1, g.fc2 = L.Linear(ptr(bufs[13]), ptr(bufs[14])), L.Linear(ptr(bufs[15]), ptr(bufs[16]))
+        return g
+
+    def _forward_nograd(self, x, y, dual):
+        b, c, h, w = x.shape
+        xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
+        ox = torch.empty_like(xn)
+        oy = torch.empty_like(yn) if dual else None
+        desc = self._desc(self.precision)
+        px = self._stream_params("x")
+        py = self._stream_params("y") if dual else None
+        lib = L.lib()
+        ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(C.byref(desc), b, h, w), x.device)
+        L.check(lib.swf_basic_block_fwd(C.byref(desc), C.byref(px), C.byref(py) if dual else None, _ptr(xn),
+                                        _ptr(yn) if dual else None, _ptr(ox), _ptr(oy) if dual else None,
+                                        b, h, w, ws, wsn, _stream(x.device)))
+        return (_to_nchw(ox), _to_nchw(oy)) if dual else (_to_nchw(ox), None)
+
+    def _backward(self, x, y, gox, goy, dual):
+        """dL/d(x, y) and the parameter gradients of both streams through swf_basic_block_bwd (exact fp32, forward recomputed)."""
+        b, c, h, w = x.shape
+        dev = x.device
+        xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
+        zeros = lambda t: torch.zeros_like(t) if t is None else t
+        gxo = _to_nhwc(gox.contiguous() if gox is not None else torch.zeros_like(x))
+        gyo = _to_nhwc(goy.contiguous() if goy is not None else torch.zeros_like(y)) if dual else None
+        gxi, gyi = torch.empty_like(xn), (torch.empty_like(yn) if dual else None)
+        streams = ("x", "y") if dual else ("x",)
+        bufs = {s: [None if t is None else torch.empty(t.shape, dtype=torch.float32, device=dev) for t in self._grad_tensors(s)] for s in streams}
+        gs = {s: self._grads_struct(bufs[s]) for s in streams}
+        desc = self._desc("fp32")
+        px = self._stream_params("x")
+        py = self._stream_params("y") if dual else None
+        lib = L.lib()
+        ws, wsn = _workspace(lib.swf_basic_block_bwd_workspace_bytes(C.byref(desc), b, h, w), dev)
+        L.check(lib.swf_basic_block_bwd(C.byref(desc), C.byref(px), C.byref(py) if dual else None, _ptr(xn), _ptr(yn) if dual else None,
+                                        _ptr(gxo), _ptr(gyo) if dual else None, _ptr(gxi), _ptr(gyi) if dual else None,
+                                        C.byref(gs["x"]), C.byref(gs["y"]) if dual else None, b, h, w, ws, wsn, _stream(dev)))
+        return _to_nchw(gxi), (_to_nchw(gyi) if dual else None), bufs
+
     def forward(self, x, y=None):
+        dual = self.use_dual_path or y is not None
+        if torch.is_grad_enabled() and (x.requires_grad or (y is not None and y.requires_grad) or
+                                        any(p.requires_grad for p in self.parameters())):
+            # autograd path: forward through the library as usual, backward through swf_basic_block_bwd (first stage of the training
+            # side: the block; patch layers, head and loss have no backward yet, so MyModel as a whole still raises)
+            for t in (x, y):
+                if t is not None and t.dim() != 4:
+                    raise ValueError(f"expected a 4-D (batch, channels, height, width) tensor, got shape {tuple(t.shape)}")
+            if self.training and (self.attention_drop_ratio or self.linear_after_att_drop_ratio or self.mlp_drop_ratio):
+                raise NotImplementedError("dropout > 0 in training mode is outside the HIP path")
+            _require_elu(self.mlp_activation_func)
+            self.check_input_compatibility_with_option(x=x, y=y)
+            streams = ("x", "y") if dual else ("x",)
+            params = [t for s in streams for t in self._grad_tensors(s)]
+            out = _BasicBlockFunction.apply(self, dual, x, y if dual else None, *params)
+            return (out[0], out[1]) if dual else out[0]
         _check_forward_only(self, x, y)
         self.check_input_compatibility_with_option(x=x, y=y)
-        dual = self.use_dual_path or y is not None
         b, c, h, w = x.shape
         xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
         ox = torch.empty_like(xn)

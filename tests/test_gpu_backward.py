@@ -1,0 +1,95 @@
+"""Training side, first stage: the backward of one BasicBlock (swf_basic_block_bwd, exact fp32) against
+torch.autograd of the CPU oracle's basic_block on the same weights and inputs — input gradients and every parameter gradient
+(LayerNorm affine, Q/K/V/projection weights and biases, the relative-position bias table, both MLP layers), both streams.  The
+reference has no backward code of its own: autograd of its forward IS its backward (a016_train.py:150-196), and the oracle is that
+forward restated (pinned to the reference by tests/test_oracle_golden.py)."""
+import pytest
+import torch
+from torch import nn
+
+import __graft_entry__ as entry
+from oracle import swin_fusion_oracle as O
+from swin_unet_image_fusion_amd import BasicBlock, load_recipe_into
+from tests import golden_util as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+_CASES = [  # C, heads, d, win, hidden, (B,H,W), shift, cross, dual
+    (8, 2, 4, 4, 32, (2, 8, 12), True, True, True),
+    (8, 2, 4, 4, 12, (1, 8, 8), False, False, True),
+    (24, 8, 3, 8, 96, (1, 16, 16), True, False, True),
+    (24, 8, 3, 8, 4, (1, 8, 16), True, True, True),          # decoder width, edge windows only
+    (12, 4, 3, 7, 24, (1, 14, 14), True, True, True),         # 7x7 windows
+    (16, 2, 8, 4, 40, (2, 8, 8), True, False, False),         # single-path block
+    (48, 8, 6, 8, 192, (1, 8, 8), True, True, True),          # one window per map: the shift mask covers most of the score tile
+]
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _built():
+    entry.build()
+    yield
+
+
+@pytest.mark.parametrize("case", _CASES, ids=[f"C{c[0]}_w{c[3]}_hid{c[4]}_s{int(c[6])}c{int(c[7])}d{int(c[8])}" for c in _CASES])
+def test_basic_block_backward_vs_autograd_of_the_oracle(case):
+    C_, nh, d, win, hid, (b, h, w), shift, cross, dual = case
+    ref_dual = BasicBlock(C_, nh, d, (win, win), shift, True, cross and dual, True, 0.0, 0.0, hid, nn.ELU(inplace=True), 0.0).eval()
+    load_recipe_into(ref_dual, seed=41, flavor="stress")
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in ref_dual.state_dict().items()}
+    x = G.randn((b, C_, h, w), 801).requires_grad_(True)
+    y = G.randn((b, C_, h, w), 802).requires_grad_(True)
+    wx, wy = G.randn((b, C_, h, w), 803), G.randn((b, C_, h, w), 804)     # a generic linear functional of the outputs as the loss
+    ox, oy = O.basic_block(sd, "", x, y, cross=cross and dual, shift=shift, num_heads=nh, dims_per_head=d, window_size=(win, win))
+    loss = (ox * wx).sum() + ((oy * wy).sum() if dual else 0.0)
+    loss.backward()
+
+    m = BasicBlock(C_, nh, d, (win, win), shift, dual, cross and dual, True, 0.0, 0.0, hid, nn.ELU(inplace=True), 0.0).eval()
+    m.load_state_dict({k: v.detach() for k, v in sd.items() if k in m.state_dict()})
+    m.to(DEV)
+    m.precision = "fp32"
+    xg = x.detach().to(DEV).requires_grad_(True)
+    yg = y.detach().to(DEV).requires_grad_(True) if dual else None
+    out = m(xg, yg) if dual else m(xg)
+    if dual:
+        (out[0] * wx.to(DEV)).sum().add((out[1] * wy.to(DEV)).sum()).backward()
+    else:
+        o0 = out[0] if isinstance(out, tuple) else out
+        (o0 * wx.to(DEV)).sum().backward()
+
+    def close(got, ref, what, scale):
+        got, ref = got.detach().cpu().double(), ref.detach().double()
+        err = float((got - ref).abs().max())
+        assert err <= 2e-4 * max(float(ref.abs().max()), scale), (what, err, float(ref.abs().max()), scale)
+
+    close(xg.grad, x.grad, "dL/dx", 0.0)
+    if dual:
+        close(yg.grad, y.grad, "dL/dy", 0.0)
+    named = dict(m.named_parameters())
+    assert named, "no parameters"
+    gscale = max(float(sd[k].grad.abs().max()) for k in named if sd[k].grad is not None)
+    checked = 0
+    for k, p in named.items():
+        assert p.grad is not None, k
+        # (gradients that vanish identically — a key bias shifts every score of a query alike — are compared on the scale of the largest)
+        close(p.grad, sd[k].grad, k, 1e-2 * gscale)
+        checked += 1
+    assert checked >= (17 if not dual else 34) - 2
+
+
+def test_backward_is_bit_reproducible():
+    """Every sum over tokens runs in a fixed order (chunked partial sums + ordered reduce, no atomics)."""
+    m = BasicBlock(24, 8, 3, (8, 8), True, True, True, True, 0.0, 0.0, 96, nn.ELU(inplace=True), 0.0).eval()
+    load_recipe_into(m, seed=42, flavor="stress")
+    m.to(DEV)
+    m.precision = "fp32"
+    x0, y0 = G.randn((2, 24, 16, 24), 811).to(DEV), G.randn((2, 24, 16, 24), 812).to(DEV)
+    grads = []
+    for _ in range(2):
+        m.zero_grad(set_to_none=True)
+        x, y = x0.clone().requires_grad_(True), y0.clone().requires_grad_(True)
+        ox, oy = m(x, y)
+        (ox.square().sum() + oy.sum()).backward()
+        grads.append([x.grad.clone(), y.grad.clone()] + [p.grad.clone() for p in m.parameters()])
+    assert all(torch.equal(a, b) for a, b in zip(*grads))

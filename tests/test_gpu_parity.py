@@ -455,6 +455,33 @@ def test_sharded_fusion_graph_replay_follows_weights_and_inputs():
     assert torch.equal(runner.fuse_global(ir2, vis2), m(ir2, vis2))
 
 
+def test_graph_runner_keeps_the_workspace_its_graph_points_into():
+    """A captured hipGraph bakes in the address of the library workspace registered for (device, capture-stream handle).  That
+    registry replaces (and frees) the buffer when a later call on the same handle needs more bytes — e.g. another model with a larger
+    shape that lands on a recycled stream handle.  The runner holds the tensor, so a replay after such a growth still reads and writes
+    live memory and equals the eager forward."""
+    from swin_unet_image_fusion_amd import modules as M
+    cfg = CONFIGS["win8_4stage"]
+    m = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(m, seed=0, flavor="default")
+    m.to(DEV)
+    runner = ShardedFusion(m, world_size=1, rank=0, use_graph=True)
+    ir, vis = (torch.from_numpy(a).to(DEV) for a in synthetic_pair(2, 128, 128, 5, 6))
+    first = runner.step(ir, vis).clone()
+    assert runner.graph_active and runner._ws_ref is not None
+    held_ptr, held_bytes = runner._ws_ref.data_ptr(), runner._ws_ref.numel()
+    key = (torch.device(DEV).index, runner._cap_stream.cuda_stream)
+    assert M._WS[key].data_ptr() == held_ptr
+    with torch.cuda.stream(runner._cap_stream):     # a later, larger request on the same stream handle
+        M._workspace(4 * held_bytes, torch.device(DEV))
+    torch.cuda.synchronize()
+    assert M._WS[key].data_ptr() != held_ptr and runner._ws_ref.data_ptr() == held_ptr     # registry moved on, the runner's buffer is alive
+    junk = torch.full((held_bytes,), 0x7F, dtype=torch.uint8, device=DEV)                  # would land on the freed block without the hold
+    again = runner.step(ir, vis)
+    assert torch.equal(again, first) and torch.equal(again, m(ir, vis))
+    del junk
+
+
 def test_pipelined_gather_on_a_one_rank_rccl_group():
     """The GPU branch of the collective (all_gather_into_tensor, async, double-buffered) on the only topology a one-GPU box
     offers: a one-rank RCCL group.  Steps are issued bench.py's way — the wait for step i comes after step i+1 was enqueued —
