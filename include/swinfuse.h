@@ -145,6 +145,7 @@ typedef struct swf_attn_grads { swf_linear_grad q, k, v, proj; float* bias_table
 typedef struct swf_block_stream_grads {
     swf_norm_grad ln1; swf_attn_grads attn; swf_norm_grad ln2; swf_linear_grad fc1, fc2;
 } swf_block_stream_grads;
+typedef struct swf_patch_grads { swf_linear_grad conv; swf_norm_grad ln; } swf_patch_grads;
 size_t swf_basic_block_bwd_workspace_bytes(const swf_block_desc* desc, int32_t B, int32_t H, int32_t W);
 int swf_basic_block_bwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                         const float* x_in, const float* y_in, const float* gx_out, const float* gy_out,
@@ -197,6 +198,22 @@ typedef struct swf_head_params {
 int swf_final_head_fwd(const swf_head_params* p, const float* x, const float* y, float* out,
                        int32_t B, int32_t H, int32_t W, int32_t ksize,
                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
+/* ---- training side, second stage: patch layers, padding, skip add ------------------------------------------------------------ */
+/* Backward of one stream of PatchMergingAndLinearLayer (a011:244-264) as the module runs it (no padding inside: MyPadding is its own
+ * module).  H x W = the layer's INPUT map: encoder the full map (divisible by the merging size), decoder the merged map.  in: the
+ * forward input [B][H][W][Cin]; gout: dL/d(output) (encoder [B][H/mh][W/mw][Cout], decoder [B][H*mh][W*mw][Cout]); gin: dL/d(input);
+ * gp: parameter gradients (overwritten; NULL pointers skipped). */
+size_t swf_patch_layer_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t merge_h, int32_t merge_w,
+                                           int32_t encoder);
+int swf_patch_layer_bwd(const swf_patch_params* p, const float* in, const float* gout, float* gin, const swf_patch_grads* gp,
+                        int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t merge_h, int32_t merge_w, int32_t encoder,
+                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
+/* Adjoint of swf_reflect_pad_fwd (MyPadding encoder side, a006:122-131): gout [B][H+pad_h][W+pad_w][C] -> gin [B][H][W][C]. */
+int swf_reflect_pad_bwd(const float* gout, float* gin, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad_h, int32_t pad_w,
+                        swf_stream_t stream);
+/* out = a + b (the decoder's skip connection, a013:222-225, when the stages run as separate modules under autograd). */
+int swf_add_fwd(const float* a, const float* b, float* out, int64_t count, swf_stream_t stream);
 
 /* AutoPathMLP.forward (a003_AutoPathMLP.py:46-50) on NHWC tokens: out = fc2(ELU(fc1(in))) per stream, no norm, no residual
  * (px / py: only fc1 and fc2 are read; py / y_* NULL for a single path).  SWF_PREC_FAST runs the level-0 width (24 channels,

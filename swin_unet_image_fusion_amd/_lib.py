@@ -85,6 +85,10 @@ SIGNATURES = {
     "swf_basic_block_bwd_workspace_bytes": (_sz, [P(BlockDesc), _i32, _i32, _i32]),
     "swf_basic_block_bwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _vp, _vp,
                                       P(BlockStreamParams), P(BlockStreamParams), _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_patch_layer_bwd_workspace_bytes": (_sz, [_i32] * 8),
+    "swf_patch_layer_bwd": (C.c_int, [P(PatchParams), _vp, _vp, _vp, P(PatchParams), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_reflect_pad_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "swf_add_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "swf_block_pair4_fwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_patch_merge_fwd": (C.c_int, [P(PatchParams), _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_merge_out_shape": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, P(_i32), P(_i32), P(_i32), P(_i32)]),

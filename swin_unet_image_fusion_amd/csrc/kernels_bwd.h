@@ -9,4 +9,11 @@ int basic_block_bwd(const swf_block_desc& d, const swf_block_stream_params* px, 
                     const float* y_in, const float* gx_out, const float* gy_out, float* gx_in, float* gy_in, const swf_block_stream_grads* gx,
                     const swf_block_stream_grads* gy, int B, int H, int W, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+// PatchMergingAndLinearLayer (one stream; H x W = the layer's input map), reflect pad, elementwise add
+size_t patch_bwd_ws(int B, int H, int W, int Cin, int Cout, int mh, int mw, int encoder);
+int patch_bwd(const swf_patch_params& p, const float* in, const float* gout, float* gin, const swf_patch_grads* gp, int B, int H, int W, int Cin,
+              int Cout, int mh, int mw, int encoder, void* workspace, size_t workspace_bytes, hipStream_t stream);
+int reflect_pad_bwd(const float* g, float* dx, int B, int H, int W, int C, int ph, int pw, hipStream_t stream);
+int add_tensors(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
+
 }  // namespace swf

@@ -346,6 +346,54 @@ int launch_attn_bwd(const AttnBwdBatch& batch, int nprob, int ld, int B, int H, 
     return fail(SWF_ERR_UNSUPPORTED, "attention backward: head_dim %d > 64", d);
 }
 
+// ---- patch layers and padding ---------------------------------------------------------------------------------------------------------
+// merged-token rows Z[(b, i, j)][(ph * mw + pw) * C + c]  <->  image [b][i * mh + ph][j * mw + pw][c] (a011:73-117): a permutation, so
+// each direction is the other's adjoint.  to_image = 1: Z -> image (depth-to-space), 0: image -> Z (space-to-depth).
+__global__ __launch_bounds__(256) void patch_permute_kernel(const float* __restrict__ src, float* __restrict__ dst, int B, int Hm, int Wm, int C,
+                                                             int mh, int mw, int to_image) {
+    const int64_t total = (int64_t)B * Hm * Wm * mh * mw * C;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    // e indexes the image [b][y][x][c]
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int W = Wm * mw, H = Hm * mh;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const int64_t z = (((int64_t)b * Hm + y / mh) * Wm + x / mw) * ((int64_t)mh * mw * C) + ((y % mh) * mw + x % mw) * C + c;
+    if (to_image) dst[e] = src[z];
+    else dst[z] = src[e];
+}
+
+// adjoint of the bottom / right reflect pad (a006:122-131, F.pad mode="reflect"): padded[H + i] = x[H - 2 - i], so input row y also
+// receives the gradient of padded row 2H - 2 - y when that row exists; columns alike.  [B][H][W][C] <- [B][H + ph][W + pw][C]
+__global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* __restrict__ g, float* __restrict__ dx, int B, int H, int W, int C,
+                                                               int ph, int pw) {
+    const int64_t total = (int64_t)B * H * W * C;
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int c = (int)(e % C);
+    int64_t r = e / C;
+    const int x = (int)(r % W); r /= W;
+    const int y = (int)(r % H);
+    const int b = (int)(r / H);
+    const int Hp = H + ph, Wp = W + pw;
+    const int y2 = 2 * H - 2 - y, x2 = 2 * W - 2 - x;
+    const bool my = y2 >= H && y2 < Hp, mx = x2 >= W && x2 < Wp;
+    auto at = [&](int yy, int xx) { return g[(((int64_t)b * Hp + yy) * Wp + xx) * C + c]; };
+    float v = at(y, x);
+    if (my) v += at(y2, x);
+    if (mx) v += at(y, x2);
+    if (my && mx) v += at(y2, x2);
+    dx[e] = v;
+}
+
+__global__ __launch_bounds__(256) void add_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ out, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) out[i] = a[i] + b[i];
+}
+
 // ---- host helpers ----------------------------------------------------------------------------------------------------------------------
 int dx(const float* dY, const float* W, float* out, int64_t M, int N, int K, int accumulate, hipStream_t st) {
     dim3 grid(cdiv(K, 64), (unsigned)cdiv64(M, 64));
@@ -498,6 +546,81 @@ int basic_block_bwd(const swf_block_desc& d, const swf_block_stream_params* px, 
     for (int s = 0; s < nstream; ++s)
         SWF_TRY(ln_bwd(xin[s], pp[s]->ln1.gamma, b[s].dxn, b[s].gx1, gin[s], G(s).ln1.gamma, G(s).ln1.beta, N, C, scratch, st));
     return SWF_OK;
+}
+
+// ---- PatchMergingAndLinearLayer backward (a011:244-264 under autograd), one stream, no window padding (the module-level layer) ----------
+size_t patch_bwd_ws(int B, int H, int W, int Cin, int Cout, int mh, int mw, int encoder) {
+    const int64_t n = encoder ? (int64_t)B * (H / mh) * (W / mw) : (int64_t)B * H * W;   // merged tokens
+    const int64_t K = encoder ? (int64_t)Cin * mh * mw : Cin, Nn = encoder ? Cout : (int64_t)Cout * mh * mw;
+    const int64_t mx = std::max(K, Nn);
+    return carve_bytes({n * K, n * Nn, n * Nn, n * Nn, n * Nn, n * K}) +
+           carve_bytes({(int64_t)chunks_of(n) * mx * (mx + 1) + (int64_t)ln_blocks(n) * 8 * Nn + 2 * Nn + 64});
+}
+
+int patch_bwd(const swf_patch_params& p, const float* in, const float* gout, float* gin, const swf_patch_grads* gp, int B, int H, int W, int Cin,
+              int Cout, int mh, int mw, int encoder, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    // H x W: the layer's INPUT map (encoder: full map, divisible by the merging size; decoder: the merged map)
+    if (encoder && (H % mh || W % mw)) return fail(SWF_ERR_BAD_SHAPE, "patch backward: map %dx%d not divisible by the merging size", H, W);
+    const int Hm = encoder ? H / mh : H, Wm = encoder ? W / mw : W;
+    const int64_t n = (int64_t)B * Hm * Wm;
+    const int K = encoder ? Cin * mh * mw : Cin, Nn = encoder ? Cout : Cout * mh * mw;
+    if (n > INT32_MAX / std::max(K, Nn)) return fail(SWF_ERR_UNSUPPORTED, "patch backward: token count");
+    Carver ws(workspace, workspace_bytes);
+    float* Z = ws.floats(n * K);      // encoder: gathered patches; decoder: unused (the input rows are Z)
+    float* U = ws.floats(n * Nn);     // conv output
+    float* V = ws.floats(n * Nn);     // LayerNorm output (decoder: in merged-token order)
+    float* A = ws.floats(n * Nn);     // ELU output in merged-token order
+    float* dV = ws.floats(n * Nn);
+    float* dZ = ws.floats(n * K);
+    const int64_t mx = std::max(K, Nn);
+    float* scratch = ws.floats((int64_t)chunks_of(n) * mx * (mx + 1) + (int64_t)ln_blocks(n) * 8 * Nn + 2 * Nn + 64);
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "patch backward workspace too small (need %zu B)", ws.used);
+    const swf_patch_grads none{};
+    const swf_patch_grads& g = gp ? *gp : none;
+    const unsigned blocks_img = (unsigned)cdiv64(n * (int64_t)mh * mw * (encoder ? Cin : Cout), 256);
+    const float* rows = in;
+    // ---- recompute: rows -> conv -> LayerNorm -> ELU (in merged-token order; ELU commutes with the depth-to-space permutation) ----
+    if (encoder) {
+        hipLaunchKernelGGL(patch_permute_kernel, dim3(blocks_img), dim3(256), 0, st, in, Z, B, Hm, Wm, Cin, mh, mw, 0);
+        SWF_TRY(check_launch("patch space-to-depth"));
+        rows = Z;
+    }
+    GemmBatch gb{};
+    gb.p[0] = GemmProb{rows, p.conv.weight, p.conv.bias, nullptr, U};
+    SWF_TRY(launch_gemm_f32(gb, 1, (int)n, Nn, K, K, Nn, 0, st));
+    LnBatch lb{};
+    lb.p[0] = LnProb{U, A, p.ln.gamma, p.ln.beta};
+    SWF_TRY(launch_layernorm(lb, 1, n, Nn, 1, st));   // A = ELU(LN(U))
+    // ---- reverse ----
+    const float* gA = gout;   // gradient w.r.t. A in merged-token order
+    if (!encoder) {           // the output image -> merged-token order
+        hipLaunchKernelGGL(patch_permute_kernel, dim3(blocks_img), dim3(256), 0, st, gout, V, B, Hm, Wm, Cout, mh, mw, 0);
+        SWF_TRY(check_launch("patch space-to-depth (gradient)"));
+        gA = V;
+    }
+    if (hipMemcpyAsync(dV, gA, (size_t)n * Nn * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SWF_ERR_HIP, "patch backward: copy failed");
+    hipLaunchKernelGGL(elu_bwd_kernel, dim3((unsigned)cdiv64(n * Nn, 256)), dim3(256), 0, st, dV, A, n * Nn);   // dV = gA . ELU'(.)
+    SWF_TRY(check_launch("elu_bwd"));
+    float* dU = V;            // (V is free again)
+    SWF_TRY(ln_bwd(U, p.ln.gamma, dV, nullptr, dU, g.ln.gamma, g.ln.beta, n, Nn, scratch, st));
+    SWF_TRY(dw(dU, rows, g.conv.weight, g.conv.bias, n, Nn, K, scratch, st));
+    if (encoder) {
+        SWF_TRY(dx(dU, p.conv.weight, dZ, n, Nn, K, 0, st));
+        hipLaunchKernelGGL(patch_permute_kernel, dim3(blocks_img), dim3(256), 0, st, dZ, gin, B, Hm, Wm, Cin, mh, mw, 1);
+        return check_launch("patch depth-to-space (gradient)");
+    }
+    return dx(dU, p.conv.weight, gin, n, Nn, K, 0, st);
+}
+
+int reflect_pad_bwd(const float* g, float* dxo, int B, int H, int W, int C, int ph, int pw, hipStream_t st) {
+    if (ph >= H || pw >= W || ph < 0 || pw < 0) return fail(SWF_ERR_PAD, "reflect pad backward: pad (%d,%d) must be smaller than the map (%d,%d)", ph, pw, H, W);
+    hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3((unsigned)cdiv64((int64_t)B * H * W * C, 256)), dim3(256), 0, st, g, dxo, B, H, W, C, ph, pw);
+    return check_launch("reflect_pad_bwd");
+}
+
+int add_tensors(const float* a, const float* b, float* out, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(add_kernel, dim3((unsigned)cdiv64(n, 256)), dim3(256), 0, st, a, b, out, n);
+    return check_launch("add");
 }
 
 }  // namespace swf

@@ -1191,6 +1191,31 @@ int swf_basic_block_bwd(const swf_block_desc* desc, const swf_block_stream_param
     return basic_block_bwd(*desc, px, py, x_in, y_in, gx_out, gy_out, gx_in, gy_in, gpx, gpy, B, H, W, workspace, workspace_bytes, as_stream(stream));
 }
 
+size_t swf_patch_layer_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t merge_h, int32_t merge_w, int32_t encoder) {
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || merge_h <= 0 || merge_w <= 0) return 0;
+    return patch_bwd_ws(B, H, W, Cin, Cout, merge_h, merge_w, encoder);
+}
+
+int swf_patch_layer_bwd(const swf_patch_params* p, const float* in, const float* gout, float* gin, const swf_patch_grads* gp, int32_t B, int32_t H,
+                        int32_t W, int32_t Cin, int32_t Cout, int32_t merge_h, int32_t merge_w, int32_t encoder, void* workspace,
+                        size_t workspace_bytes, swf_stream_t stream) {
+    if (!p || !p->conv.weight || !p->ln.gamma || !p->ln.beta || !in || !gout || !gin) return fail(SWF_ERR_NULL, "patch_layer_bwd: NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || merge_h <= 0 || merge_w <= 0) return fail(SWF_ERR_BAD_SHAPE, "patch_layer_bwd: bad sizes");
+    return patch_bwd(*p, in, gout, gin, gp, B, H, W, Cin, Cout, merge_h, merge_w, encoder, workspace, workspace_bytes, as_stream(stream));
+}
+
+int swf_reflect_pad_bwd(const float* gout, float* gin, int32_t B, int32_t H, int32_t W, int32_t C, int32_t pad_h, int32_t pad_w, swf_stream_t stream) {
+    if (!gout || !gin) return fail(SWF_ERR_NULL, "reflect_pad_bwd: NULL tensor");
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0) return fail(SWF_ERR_BAD_SHAPE, "reflect_pad_bwd: empty tensor");
+    return reflect_pad_bwd(gout, gin, B, H, W, C, pad_h, pad_w, as_stream(stream));
+}
+
+int swf_add_fwd(const float* a, const float* b, float* out, int64_t count, swf_stream_t stream) {
+    if (!a || !b || !out) return fail(SWF_ERR_NULL, "add: NULL tensor");
+    if (count <= 0) return fail(SWF_ERR_BAD_SHAPE, "add: empty tensor");
+    return add_tensors(a, b, out, count, as_stream(stream));
+}
+
 int swf_block_pair4_fwd(const swf_block_desc* desc, const swf_block_stream_params* px, const swf_block_stream_params* py,
                         const float* x_in, const float* y_in, float* x_out, float* y_out, int32_t B, int32_t H, int32_t W,
                         void* workspace, size_t workspace_bytes, swf_stream_t stream) {

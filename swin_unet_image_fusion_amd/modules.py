@@ -93,6 +93,12 @@ def _check_forward_only(module: nn.Module, *tensors: Optional[Tensor]) -> None:
             raise ValueError(f"expected a 4-D (batch, channels, height, width) tensor, got shape {tuple(t.shape)}")
 
 
+def _wants_grad(module: nn.Module, *tensors: Optional[Tensor]) -> bool:
+    """True when torch.autograd is recording and an input or a parameter of `module` takes part in it (training side)."""
+    return torch.is_grad_enabled() and (any(t is not None and t.requires_grad for t in tensors) or
+                                        any(p.requires_grad for p in module.parameters()))
+
+
 def _to_nhwc(t: Tensor) -> Tensor:
     b, c, h, w = t.shape
     t = t.contiguous()
@@ -599,6 +605,62 @@ class SelfAndCrossBlockPair(_FwdAlias, nn.Module):
 # ----------------------------------------------------------------------------------------------
 # a006 / a011: padding and patch (un)merging
 # ----------------------------------------------------------------------------------------------
+class _ReflectPadFunction(torch.autograd.Function):
+    """MyPadding encoder side under autograd: forward swf_reflect_pad_fwd, backward its adjoint swf_reflect_pad_bwd."""
+
+    @staticmethod
+    def forward(ctx, t, ph, pw):
+        b, c, h, w = t.shape
+        ctx.shape, ctx.pad = (b, c, h, w), (ph, pw)
+        t = t.contiguous()
+        out = torch.empty((b, c, h + ph, w + pw), dtype=torch.float32, device=t.device)
+        L.check(L.lib().swf_reflect_pad_fwd(_ptr(t), _ptr(out), b * c, h, w, 1, ph, pw, _stream(t.device)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        (b, c, h, w), (ph, pw) = ctx.shape, ctx.pad
+        g = g.contiguous()
+        dx = torch.empty((b, c, h, w), dtype=torch.float32, device=g.device)
+        L.check(L.lib().swf_reflect_pad_bwd(_ptr(g), _ptr(dx), b * c, h, w, 1, ph, pw, _stream(g.device)))
+        return dx, None, None
+
+
+class _CropFunction(torch.autograd.Function):
+    """MyPadding decoder side under autograd: forward swf_crop_fwd, backward the zero padding of the cropped rows / columns (a copy)."""
+
+    @staticmethod
+    def forward(ctx, t, ph, pw):
+        b, c, h, w = t.shape
+        ctx.shape = (b, c, h, w)
+        t = t.contiguous()
+        out = torch.empty((b, c, h - ph, w - pw), dtype=torch.float32, device=t.device)
+        L.check(L.lib().swf_crop_fwd(_ptr(t), _ptr(out), b * c, h, w, h - ph, w - pw, 1, _stream(t.device)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        b, c, h, w = ctx.shape
+        dx = torch.zeros((b, c, h, w), dtype=torch.float32, device=g.device)
+        dx[:, :, : g.shape[2], : g.shape[3]].copy_(g)
+        return dx, None, None
+
+
+class _AddFunction(torch.autograd.Function):
+    """The decoder's skip connection (a013:222-225) as a library call; both inputs receive the output gradient."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        a, b = a.contiguous(), b.contiguous()
+        out = torch.empty_like(a)
+        L.check(L.lib().swf_add_fwd(_ptr(a), _ptr(b), _ptr(out), a.numel(), _stream(a.device)))
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 class MyPadding(_FwdAlias, nn.Module):
     """a006_PaddingOperation.MyPadding: encoder side reflect-pads bottom/right to a multiple of
     `window_size` and pushes (shape, pad) on the shared recorders; decoder side pops and crops."""
@@ -619,6 +681,10 @@ class MyPadding(_FwdAlias, nn.Module):
         ph, pw = self.padding_size
         if ph == 0 and pw == 0:
             return t
+        if torch.is_grad_enabled() and t.requires_grad:
+            if ph >= t.shape[2] or pw >= t.shape[3]:
+                raise RuntimeError(f"reflect pad ({ph},{pw}) must be smaller than the map {tuple(t.shape[2:])} (a006:128)")
+            return _ReflectPadFunction.apply(t, ph, pw)
         b, c, h, w = t.shape
         t = t.contiguous()
         out = torch.empty((b, c, h + ph, w + pw), dtype=torch.float32, device=t.device)
@@ -630,6 +696,8 @@ class MyPadding(_FwdAlias, nn.Module):
         ph, pw = self.padding_size
         if ph == 0 and pw == 0:
             return t
+        if torch.is_grad_enabled() and t.requires_grad:
+            return _CropFunction.apply(t, ph, pw)
         b, c, h, w = t.shape
         t = t.contiguous()
         out = torch.empty((b, c, h - ph, w - pw), dtype=torch.float32, device=t.device)
@@ -637,7 +705,8 @@ class MyPadding(_FwdAlias, nn.Module):
         return out
 
     def forward(self, x, y):
-        _check_forward_only(self, x, y)
+        if not _wants_grad(self, x, y):
+            _check_forward_only(self, x, y)
         if self.belongs_to_encoder:
             h, w = x.shape[-2:]
             if not (self.training and self.feature_shape_hw):   # a006:38-52: refreshed every call in eval
@@ -656,6 +725,39 @@ class MyPadding(_FwdAlias, nn.Module):
         if self.use_dual_path:
             return op(x), (op(y) if y is not None else None)
         return op(x)
+
+
+class _PatchLayerFunction(torch.autograd.Function):
+    """One stream of PatchMergingAndLinearLayer under autograd: forward through the library, backward = swf_patch_layer_bwd."""
+
+    @staticmethod
+    def forward(ctx, layer, s, t, cw, cb, lg, lb):
+        ctx.layer, ctx.s = layer, s
+        ctx.save_for_backward(t)
+        with torch.no_grad():
+            return layer._one(t.detach(), s)
+
+    @staticmethod
+    def backward(ctx, g):
+        layer, s = ctx.layer, ctx.s
+        (t,) = ctx.saved_tensors
+        b, c, h, w = t.shape
+        mh, mw = layer.merging_or_unmerging_size
+        conv, ln = getattr(layer, f"mlp_layer_{s}"), getattr(layer, f"layer_norm_{s}")
+        dev = t.device
+        with torch.no_grad():
+            tn, gn = _to_nhwc(t), _to_nhwc(g.contiguous())
+            gin = torch.empty_like(tn)
+            gw = torch.empty(conv.weight.shape, dtype=torch.float32, device=dev)
+            gb = torch.empty(conv.bias.shape, dtype=torch.float32, device=dev) if conv.bias is not None else None
+            gg, gbe = torch.empty_like(ln.weight), torch.empty_like(ln.bias)
+            prm = L.PatchParams(_lin(conv), _norm(ln))
+            grads = L.PatchParams(L.Linear(gw.data_ptr(), gb.data_ptr() if gb is not None else None), L.Norm(gg.data_ptr(), gbe.data_ptr()))
+            lib, enc = L.lib(), int(layer.belongs_to_encoder)
+            ws, wsn = _workspace(lib.swf_patch_layer_bwd_workspace_bytes(b, h, w, layer.in_dims, layer.out_dims, mh, mw, enc), dev)
+            L.check(lib.swf_patch_layer_bwd(C.byref(prm), _ptr(tn), _ptr(gn), _ptr(gin), C.byref(grads), b, h, w, layer.in_dims, layer.out_dims,
+                                            mh, mw, enc, ws, wsn, _stream(dev)))
+            return None, None, _to_nchw(gin), gw, gb, gg, gbe
 
 
 class PatchMergingAndLinearLayer(_FwdAlias, nn.Module):
@@ -701,13 +803,20 @@ class PatchMergingAndLinearLayer(_FwdAlias, nn.Module):
                                               self.out_dims, mh, mw, h * mh, w * mw, ws, wsn, _stream(t.device)))
         return _to_nchw(out)
 
+    def _one_grad(self, t: Tensor, s: str) -> Tensor:
+        conv, ln = getattr(self, f"mlp_layer_{s}"), getattr(self, f"layer_norm_{s}")
+        return _PatchLayerFunction.apply(self, s, t, conv.weight, conv.bias, ln.weight, ln.bias)
+
     def forward(self, x, y=None):
-        _check_forward_only(self, x, y)
+        grad = _wants_grad(self, x, y)
+        if not grad:
+            _check_forward_only(self, x, y)
         if x.shape[1] != self.in_dims:
             raise RuntimeError(f"expected {self.in_dims} channels, got {x.shape[1]}")
+        one = self._one_grad if grad else self._one
         if y is not None:
-            return self._one(x, "x"), self._one(y, "y")
-        return self._one(x, "x")
+            return one(x, "x"), one(y, "y")
+        return one(x, "x")
 
 
 # ----------------------------------------------------------------------------------------------

@@ -9,7 +9,7 @@ from torch import nn
 
 import __graft_entry__ as entry
 from oracle import swin_fusion_oracle as O
-from swin_unet_image_fusion_amd import BasicBlock, load_recipe_into
+from swin_unet_image_fusion_amd import BasicBlock, MyPadding, PatchMergingAndLinearLayer, StateRecorder, load_recipe_into
 from tests import golden_util as G
 
 pytestmark = pytest.mark.gpu
@@ -93,3 +93,47 @@ def test_backward_is_bit_reproducible():
         (ox.square().sum() + oy.sum()).backward()
         grads.append([x.grad.clone(), y.grad.clone()] + [p.grad.clone() for p in m.parameters()])
     assert all(torch.equal(a, b) for a, b in zip(*grads))
+
+
+@pytest.mark.parametrize("enc,cin,cout,shape", [(True, 1, 24, (2, 16, 12)), (True, 8, 16, (1, 8, 8)), (False, 16, 8, (1, 4, 6)), (False, 24, 1, (2, 8, 8)),
+                                                (True, 96, 192, (1, 4, 4)), (False, 384, 192, (1, 2, 2))])
+def test_patch_layer_backward_vs_autograd_of_the_oracle(enc, cin, cout, shape):
+    """PatchMergingAndLinearLayer (a011:244-264) under autograd: input and parameter gradients of both streams."""
+    b, h, w = shape
+    m = PatchMergingAndLinearLayer(belongs_to_encoder=enc, use_dual_path=True, in_dims=cin, out_dims=cout, patch_merging_size_recorder=StateRecorder(),
+                                   merging_or_unmerging_size=(2, 2), activation_func=nn.ELU(inplace=True)).eval()
+    load_recipe_into(m, seed=43, flavor="stress")
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point()) for k, v in m.state_dict().items()}
+    x, y = G.randn((b, cin, h, w), 821).requires_grad_(True), G.randn((b, cin, h, w), 822).requires_grad_(True)
+    ox, oy = O.patch_layer(sd, "", x, y, encoder=enc, merging_size=(2, 2))
+    wx, wy = G.randn(tuple(ox.shape), 823), G.randn(tuple(oy.shape), 824)
+    ((ox * wx).sum() + (oy * wy).sum()).backward()
+    m.to(DEV)
+    xg, yg = x.detach().to(DEV).requires_grad_(True), y.detach().to(DEV).requires_grad_(True)
+    gx, gy = m(xg, yg)
+    ((gx * wx.to(DEV)).sum() + (gy * wy.to(DEV)).sum()).backward()
+
+    def close(got, ref, what):
+        got, ref = got.detach().cpu().double(), ref.detach().double()
+        assert float((got - ref).abs().max()) <= 2e-4 * max(float(ref.abs().max()), 1e-3), (what, float((got - ref).abs().max()), float(ref.abs().max()))
+
+    close(xg.grad, x.grad, "dL/dx"); close(yg.grad, y.grad, "dL/dy")
+    for k, p in m.named_parameters():
+        close(p.grad, sd[k].grad, k)
+
+
+@pytest.mark.parametrize("win,shape", [((7, 7), (1, 3, 10, 13)), ((2, 2), (2, 2, 5, 4)), ((8, 8), (1, 2, 16, 16)), ((4, 4), (1, 1, 6, 7))])
+def test_padding_backward_vs_autograd_of_the_oracle(win, shape):
+    """MyPadding (a006:122-146) under autograd: reflect pad then crop, and the pad alone."""
+    fr, pr = StateRecorder(), StateRecorder()
+    enc, dec = MyPadding(True, win, True, fr, pr).eval(), MyPadding(False, win, True, fr, pr).eval()
+    x, y = G.randn(shape, 831).requires_grad_(True), G.randn(shape, 832).requires_grad_(True)
+    px, pad = O.pad_to_multiple(x, win)
+    py, _ = O.pad_to_multiple(y, win)
+    wx, wy = G.randn(tuple(px.shape), 833), G.randn(tuple(py.shape), 834)
+    ((px * wx).sum() + (py * wy).sum() + O.crop_padding(px * 2.0, pad).sum()).backward()
+    xg, yg = x.detach().to(DEV).requires_grad_(True), y.detach().to(DEV).requires_grad_(True)
+    gx, gy = enc(xg, yg)
+    cx, _ = dec(gx * 2.0, gy)
+    ((gx * wx.to(DEV)).sum() + (gy * wy.to(DEV)).sum() + cx.sum()).backward()
+    assert torch.allclose(xg.grad.cpu(), x.grad, rtol=1e-5, atol=1e-6) and torch.allclose(yg.grad.cpu(), y.grad, rtol=1e-5, atol=1e-6)
