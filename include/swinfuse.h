@@ -199,6 +199,17 @@ int swf_final_head_fwd(const swf_head_params* p, const float* x, const float* y,
                        int32_t B, int32_t H, int32_t W, int32_t ksize,
                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
 
+/* Backward of the final head with BatchNorm in eval mode (running statistics: a per-channel affine map).  gout: dL/d(out) [B][H][W];
+ * gx / gy: dL/d(x), dL/d(y); gp: parameter gradients (overwritten; NULL pointers skipped; the running statistics have none).  Reads
+ * the eight BatchNorm scalars back to the host: synchronises the stream once. */
+typedef struct swf_head_grads {
+    float* conv1_w; float* conv1_b; float* bn_gamma; float* bn_beta; float* conv2_w; float* conv2_b;
+} swf_head_grads;
+size_t swf_final_head_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t ksize);
+int swf_final_head_bwd(const swf_head_params* p, const float* x, const float* y, const float* gout, float* gx, float* gy,
+                       const swf_head_grads* gp, int32_t B, int32_t H, int32_t W, int32_t ksize,
+                       void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
 /* ---- training side, second stage: patch layers, padding, skip add ------------------------------------------------------------ */
 /* Backward of one stream of PatchMergingAndLinearLayer (a011:244-264) as the module runs it (no padding inside: MyPadding is its own
  * module).  H x W = the layer's INPUT map: encoder the full map (divisible by the merging size), decoder the merged map.  in: the

@@ -57,6 +57,11 @@ class HeadParams(C.Structure):
                 ("bn_mean", C.c_void_p), ("bn_var", C.c_void_p), ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p)]
 
 
+class HeadGrads(C.Structure):
+    _fields_ = [("conv1_w", C.c_void_p), ("conv1_b", C.c_void_p), ("bn_gamma", C.c_void_p), ("bn_beta", C.c_void_p),
+                ("conv2_w", C.c_void_p), ("conv2_b", C.c_void_p)]
+
+
 class ModelDesc(C.Structure):
     _fields_ = [("levels", C.c_int32), ("in_dims", C.c_int32 * SWF_MAX_LEVELS), ("out_dims", C.c_int32 * SWF_MAX_LEVELS),
                 ("heads", C.c_int32), ("head_dim", C.c_int32 * SWF_MAX_LEVELS), ("mlp_ratio", C.c_int32),
@@ -88,6 +93,8 @@ SIGNATURES = {
     "swf_patch_layer_bwd_workspace_bytes": (_sz, [_i32] * 8),
     "swf_patch_layer_bwd": (C.c_int, [P(PatchParams), _vp, _vp, _vp, P(PatchParams), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_reflect_pad_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "swf_final_head_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
+    "swf_final_head_bwd": (C.c_int, [P(HeadParams), _vp, _vp, _vp, _vp, _vp, P(HeadGrads), _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_add_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "swf_block_pair4_fwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_patch_merge_fwd": (C.c_int, [P(PatchParams), _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),

@@ -16,4 +16,9 @@ int patch_bwd(const swf_patch_params& p, const float* in, const float* gout, flo
 int reflect_pad_bwd(const float* g, float* dx, int B, int H, int W, int C, int ph, int pw, hipStream_t stream);
 int add_tensors(const float* a, const float* b, float* out, int64_t n, hipStream_t stream);
 
+// final head (BatchNorm in eval mode)
+size_t head_bwd_ws(int B, int H, int W, int ks);
+int head_bwd(const swf_head_params& p, const float* x, const float* y, const float* gout, float* gx, float* gy, const swf_head_grads* gp, int B,
+             int H, int W, int ks, void* workspace, size_t workspace_bytes, hipStream_t stream);
+
 }  // namespace swf

@@ -623,4 +623,196 @@ int add_tensors(const float* a, const float* b, float* out, int64_t n, hipStream
     return check_launch("add");
 }
 
+// ---- final head backward (a013:126-152 under autograd; BatchNorm in eval mode = a per-channel affine map of its running statistics) ------
+// forward:  t1 = conv1(cat(x, y)) [2 ch];  t2 = a t1 + c,  a = gamma / sqrt(var + eps),  c = beta - mean a;  t3 = ELU(t2);  out = conv2(t3)
+// Both convolutions read reflect-padded maps ('same', padding_mode='reflect'): the adjoint folds the padded gradient back, here in gather
+// form — a pixel sums over every (output pixel, tap) pair whose reflected source it is — so every sum has a fixed order.
+namespace {
+
+__device__ __forceinline__ int reflect2b(int i, int n) { return i < 0 ? -i : (i >= n ? 2 * n - 2 - i : i); }
+
+__global__ __launch_bounds__(256) void head_t1_kernel(const float* __restrict__ x, const float* __restrict__ y, float* __restrict__ t1,
+                                                       swf_head_params p, int B, int H, int W, int ks) {
+    const int64_t total = (int64_t)B * H * W, e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int r = ks / 2, px = (int)(e % W), py = (int)((e / W) % H);
+    const int64_t b = e / ((int64_t)W * H);
+    float a0 = p.conv1_b ? p.conv1_b[0] : 0.f, a1 = p.conv1_b ? p.conv1_b[1] : 0.f;
+    for (int ky = 0; ky < ks; ++ky) {
+        const int yy = reflect2b(py + ky - r, H);
+        for (int kx = 0; kx < ks; ++kx) {
+            const int xx = reflect2b(px + kx - r, W);
+            const int64_t sidx = (b * H + yy) * W + xx;
+            const float vx = x[sidx], vy = y[sidx];
+            a0 = fmaf(p.conv1_w[((0 * 2 + 0) * ks + ky) * ks + kx], vx, a0);
+            a0 = fmaf(p.conv1_w[((0 * 2 + 1) * ks + ky) * ks + kx], vy, a0);
+            a1 = fmaf(p.conv1_w[((1 * 2 + 0) * ks + ky) * ks + kx], vx, a1);
+            a1 = fmaf(p.conv1_w[((1 * 2 + 1) * ks + ky) * ks + kx], vy, a1);
+        }
+    }
+    t1[2 * e] = a0; t1[2 * e + 1] = a1;
+}
+
+// out[pixel][ci] = sum over (output pixel o, tap k) with reflect(o + k - r) == pixel of g[o][co] w[co][ci][k]: the adjoint of a reflect-'same'
+// convolution with CO output and 2 input channels.  post != 0: multiply channel ci by ELU'(a[ci] t1[ci] + c[ci]) (the head's dt2).
+__global__ __launch_bounds__(256) void head_conv_adjoint_kernel(const float* __restrict__ g, const float* __restrict__ w, float* __restrict__ out,
+                                                                 int CO, const float* __restrict__ t1, float a0, float c0, float a1, float c1,
+                                                                 int post, int B, int H, int W, int ks) {
+    const int64_t total = (int64_t)B * H * W, e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int r = ks / 2, px = (int)(e % W), py = (int)((e / W) % H);
+    const int64_t b = e / ((int64_t)W * H);
+    float acc[2] = {0.f, 0.f};
+    for (int oy = max(0, py - 2 * r); oy <= min(H - 1, py + 2 * r); ++oy)
+        for (int ky = 0; ky < ks; ++ky) {
+            if (reflect2b(oy + ky - r, H) != py) continue;
+            for (int ox = max(0, px - 2 * r); ox <= min(W - 1, px + 2 * r); ++ox)
+                for (int kx = 0; kx < ks; ++kx) {
+                    if (reflect2b(ox + kx - r, W) != px) continue;
+                    const int64_t o = (b * H + oy) * W + ox;
+                    for (int co = 0; co < CO; ++co) {
+                        const float gv = g[o * CO + co];
+                        acc[0] = fmaf(gv, w[((co * 2 + 0) * ks + ky) * ks + kx], acc[0]);
+                        acc[1] = fmaf(gv, w[((co * 2 + 1) * ks + ky) * ks + kx], acc[1]);
+                    }
+                }
+        }
+    if (post) {
+        const float u0 = a0 * t1[2 * e] + c0, u1 = a1 * t1[2 * e + 1] + c1;
+        acc[0] *= u0 > 0.f ? 1.0f : expf(u0);
+        acc[1] *= u1 > 0.f ? 1.0f : expf(u1);
+    }
+    out[2 * e] = acc[0]; out[2 * e + 1] = acc[1];
+}
+
+// per-pixel rows whose column sums are the conv2 gradients: [ci][ky][kx] gout t3(reflected source), then gout (bias)
+__global__ __launch_bounds__(256) void head_rows2_kernel(const float* __restrict__ gout, const float* __restrict__ t1, float* __restrict__ rows,
+                                                          float a0, float c0, float a1, float c1, int B, int H, int W, int ks) {
+    const int64_t total = (int64_t)B * H * W, e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int r = ks / 2, px = (int)(e % W), py = (int)((e / W) % H), NC = 2 * ks * ks + 1;
+    const int64_t b = e / ((int64_t)W * H);
+    const float g = gout[e];
+    float* row = rows + e * NC;
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            const int64_t sidx = (b * H + reflect2b(py + ky - r, H)) * W + reflect2b(px + kx - r, W);
+            const float u0 = a0 * t1[2 * sidx] + c0, u1 = a1 * t1[2 * sidx + 1] + c1;
+            row[(0 * ks + ky) * ks + kx] = g * (u0 > 0.f ? u0 : expm1f(u0));
+            row[(1 * ks + ky) * ks + kx] = g * (u1 > 0.f ? u1 : expm1f(u1));
+        }
+    row[NC - 1] = g;
+}
+
+// per-pixel rows for conv1 / BatchNorm gradients: [co][ci][ky][kx] dt1[co] in[ci](reflected source), dt1[0..1] (conv1 bias),
+// dt2[c] xhat[c] (gamma), dt2[c] (beta)
+__global__ __launch_bounds__(256) void head_rows1_kernel(const float* __restrict__ dt2, const float* __restrict__ t1, const float* __restrict__ x,
+                                                          const float* __restrict__ y, float* __restrict__ rows, float a0, float a1, float m0,
+                                                          float m1, float is0, float is1, int B, int H, int W, int ks) {
+    const int64_t total = (int64_t)B * H * W, e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= total) return;
+    const int r = ks / 2, px = (int)(e % W), py = (int)((e / W) % H), NC = 4 * ks * ks + 6;
+    const int64_t b = e / ((int64_t)W * H);
+    const float d0 = dt2[2 * e], d1 = dt2[2 * e + 1], g0 = d0 * a0, g1 = d1 * a1;   // dt1 = dt2 a
+    float* row = rows + e * NC;
+    for (int ky = 0; ky < ks; ++ky)
+        for (int kx = 0; kx < ks; ++kx) {
+            const int64_t sidx = (b * H + reflect2b(py + ky - r, H)) * W + reflect2b(px + kx - r, W);
+            const float vx = x[sidx], vy = y[sidx];
+            row[((0 * 2 + 0) * ks + ky) * ks + kx] = g0 * vx;
+            row[((0 * 2 + 1) * ks + ky) * ks + kx] = g0 * vy;
+            row[((1 * 2 + 0) * ks + ky) * ks + kx] = g1 * vx;
+            row[((1 * 2 + 1) * ks + ky) * ks + kx] = g1 * vy;
+        }
+    row[4 * ks * ks] = g0; row[4 * ks * ks + 1] = g1;
+    row[4 * ks * ks + 2] = d0 * (t1[2 * e] - m0) * is0; row[4 * ks * ks + 3] = d1 * (t1[2 * e + 1] - m1) * is1;
+    row[4 * ks * ks + 4] = d0; row[4 * ks * ks + 5] = d1;
+}
+
+__global__ __launch_bounds__(256) void head_scale2_kernel(const float* __restrict__ in, float* __restrict__ out, float a0, float a1, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) { out[2 * e] = in[2 * e] * a0; out[2 * e + 1] = in[2 * e + 1] * a1; }
+}
+
+__global__ __launch_bounds__(256) void head_split_kernel(const float* __restrict__ g2, float* __restrict__ gx, float* __restrict__ gy, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e < n) { gx[e] = g2[2 * e]; gy[e] = g2[2 * e + 1]; }
+}
+
+}  // namespace
+
+size_t head_bwd_ws(int B, int H, int W, int ks) {
+    const int64_t n = (int64_t)B * H * W, nc = 4 * ks * ks + 6;
+    return carve_bytes({2 * n, 2 * n, 2 * n, n * nc, (int64_t)chunks_of(n) * nc + nc + 64});
+}
+
+int head_bwd(const swf_head_params& p, const float* x, const float* y, const float* gout, float* gx, float* gy, const swf_head_grads* gp, int B,
+             int H, int W, int ks, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (ks < 1 || ks % 2 == 0 || ks / 2 >= H || ks / 2 >= W) return fail(SWF_ERR_PAD, "head backward: kernel %d on a %dx%d map", ks, H, W);
+    const int64_t n = (int64_t)B * H * W;
+    const int nc1 = 4 * ks * ks + 6, nc2 = 2 * ks * ks + 1;
+    Carver ws(workspace, workspace_bytes);
+    float* t1 = ws.floats(2 * n);
+    float* dt2 = ws.floats(2 * n);
+    float* din = ws.floats(2 * n);
+    float* rows = ws.floats(n * nc1);
+    float* part = ws.floats((int64_t)chunks_of(n) * nc1 + nc1 + 64);
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "head backward workspace too small (need %zu B)", ws.used);
+    // the BatchNorm constants are four scalars per channel: read them on the host once (a 32-byte synchronous copy per call)
+    float hg[2], hb[2], hm[2], hv[2];
+    if (hipMemcpyAsync(hg, p.bn_gamma, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hb, p.bn_beta, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipMemcpyAsync(hm, p.bn_mean, 8, hipMemcpyDeviceToHost, st) != hipSuccess || hipMemcpyAsync(hv, p.bn_var, 8, hipMemcpyDeviceToHost, st) != hipSuccess ||
+        hipStreamSynchronize(st) != hipSuccess)
+        return fail(SWF_ERR_HIP, "head backward: reading the BatchNorm constants failed");
+    float a[2], c[2], is[2];
+    for (int i = 0; i < 2; ++i) { is[i] = 1.0f / sqrtf(hv[i] + 1e-5f); a[i] = hg[i] * is[i]; c[i] = hb[i] - hm[i] * a[i]; }
+    const unsigned blocks = (unsigned)cdiv64(n, 256);
+    const swf_head_grads none{};
+    const swf_head_grads& g = gp ? *gp : none;
+    hipLaunchKernelGGL(head_t1_kernel, dim3(blocks), dim3(256), 0, st, x, y, t1, p, B, H, W, ks);
+    SWF_TRY(check_launch("head_t1"));
+    // dt2 = adjoint(conv2)(gout) . ELU'(t2)
+    hipLaunchKernelGGL(head_conv_adjoint_kernel, dim3(blocks), dim3(256), 0, st, gout, p.conv2_w, dt2, 1, t1, a[0], c[0], a[1], c[1], 1, B, H, W, ks);
+    SWF_TRY(check_launch("head adjoint conv2"));
+    auto colsums = [&](int nc, float* out_host_layout) -> int {   // column sums of rows [n][nc] -> part tail (device)
+        const int ch = chunks_of(n);
+        hipLaunchKernelGGL(bwd_colsum_kernel, dim3(cdiv(nc, 256), ch), dim3(256), 0, st, rows, part, (int)n, nc);
+        SWF_TRY(check_launch("head colsum"));
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(nc, 256)), dim3(256), 0, st, part, out_host_layout, (int64_t)nc, ch);
+        return check_launch("head colsum reduce");
+    };
+    float* sums = part + (int64_t)chunks_of(n) * nc1;
+    auto copy = [&](float* dst, const float* src, int count) -> int {
+        if (!dst) return SWF_OK;
+        return hipMemcpyAsync(dst, src, (size_t)count * 4, hipMemcpyDeviceToDevice, st) == hipSuccess ? SWF_OK : fail(SWF_ERR_HIP, "head backward: copy failed");
+    };
+    if (g.conv2_w || g.conv2_b) {
+        hipLaunchKernelGGL(head_rows2_kernel, dim3(blocks), dim3(256), 0, st, gout, t1, rows, a[0], c[0], a[1], c[1], B, H, W, ks);
+        SWF_TRY(check_launch("head rows2"));
+        SWF_TRY(colsums(nc2, sums));
+        SWF_TRY(copy(g.conv2_w, sums, 2 * ks * ks));
+        SWF_TRY(copy(g.conv2_b, sums + 2 * ks * ks, 1));
+    }
+    hipLaunchKernelGGL(head_rows1_kernel, dim3(blocks), dim3(256), 0, st, dt2, t1, x, y, rows, a[0], a[1], hm[0], hm[1], is[0], is[1], B, H, W, ks);
+    SWF_TRY(check_launch("head rows1"));
+    SWF_TRY(colsums(nc1, sums));
+    SWF_TRY(copy(g.conv1_w, sums, 4 * ks * ks));
+    SWF_TRY(copy(g.conv1_b, sums + 4 * ks * ks, 2));
+    SWF_TRY(copy(g.bn_gamma, sums + 4 * ks * ks + 2, 2));
+    SWF_TRY(copy(g.bn_beta, sums + 4 * ks * ks + 4, 2));
+    // d(cat(x, y)) = adjoint(conv1)(dt1), dt1 = dt2 a: fold a into the weights' side by scaling dt2 in place
+    // (dt2 is not needed afterwards)
+    {
+        // scale channel c of dt2 by a[c] with the split kernel's twin: reuse head_conv_adjoint's generic form on pre-scaled gradients
+        // through rows as scratch: rows[e*2+c] = dt2[e*2+c] * a[c]
+        float* dt1 = rows;
+        hipLaunchKernelGGL(head_scale2_kernel, dim3(blocks), dim3(256), 0, st, dt2, dt1, a[0], a[1], n);
+        SWF_TRY(check_launch("head dt1"));
+        hipLaunchKernelGGL(head_conv_adjoint_kernel, dim3(blocks), dim3(256), 0, st, dt1, p.conv1_w, din, 2, t1, 0.f, 0.f, 0.f, 0.f, 0, B, H, W, ks);
+        SWF_TRY(check_launch("head adjoint conv1"));
+    }
+    hipLaunchKernelGGL(head_split_kernel, dim3(blocks), dim3(256), 0, st, din, gx, gy, n);
+    return check_launch("head split");
+}
+
 }  // namespace swf

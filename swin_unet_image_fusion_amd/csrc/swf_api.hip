@@ -1210,6 +1210,19 @@ int swf_reflect_pad_bwd(const float* gout, float* gin, int32_t B, int32_t H, int
     return reflect_pad_bwd(gout, gin, B, H, W, C, pad_h, pad_w, as_stream(stream));
 }
 
+size_t swf_final_head_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t ksize) {
+    if (B <= 0 || H <= 0 || W <= 0 || ksize <= 0) return 0;
+    return head_bwd_ws(B, H, W, ksize);
+}
+
+int swf_final_head_bwd(const swf_head_params* p, const float* x, const float* y, const float* gout, float* gx, float* gy, const swf_head_grads* gp,
+                       int32_t B, int32_t H, int32_t W, int32_t ksize, void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    if (!p || !p->conv1_w || !p->conv2_w || !p->bn_gamma || !p->bn_beta || !p->bn_mean || !p->bn_var || !x || !y || !gout || !gx || !gy)
+        return fail(SWF_ERR_NULL, "final_head_bwd: NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(SWF_ERR_BAD_SHAPE, "final_head_bwd: empty tensor");
+    return head_bwd(*p, x, y, gout, gx, gy, gp, B, H, W, ksize, workspace, workspace_bytes, as_stream(stream));
+}
+
 int swf_add_fwd(const float* a, const float* b, float* out, int64_t count, swf_stream_t stream) {
     if (!a || !b || !out) return fail(SWF_ERR_NULL, "add: NULL tensor");
     if (count <= 0) return fail(SWF_ERR_BAD_SHAPE, "add: empty tensor");

@@ -582,11 +582,18 @@ class SelfAndCrossBlockPair(_FwdAlias, nn.Module):
                 self.cross_att_block.normal_window_block, self.cross_att_block.shifted_window_block]
 
     def forward(self, x, y=None):
-        _check_forward_only(self, x, y)
         blocks = self._blocks()
         dual = self.use_dual_path
         if dual and y is None:
             raise ValueError("use_dual_path=True needs both x and y")
+        if _wants_grad(self, x, y):   # under autograd the four blocks run one by one (each differentiable: BasicBlock.forward)
+            for blk in blocks:
+                if dual:
+                    x, y = blk(x, y)
+                else:
+                    x = blk(x)
+            return (x, y) if dual else x
+        _check_forward_only(self, x, y)
         blocks[2].check_input_compatibility_with_option(x=x, y=y if dual else None)
         b, c, h, w = x.shape
         xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
@@ -822,6 +829,41 @@ class PatchMergingAndLinearLayer(_FwdAlias, nn.Module):
 # ----------------------------------------------------------------------------------------------
 # a013: model assembly
 # ----------------------------------------------------------------------------------------------
+class _HeadFunction(torch.autograd.Function):
+    """MyModel.do_final_layer (a013:126-152) under autograd, BatchNorm in eval mode: forward swf_final_head_fwd, backward swf_final_head_bwd."""
+
+    @staticmethod
+    def forward(ctx, model, x, y, c1w, c1b, g, bt, c2w, c2b):
+        ctx.model = model
+        ctx.save_for_backward(x, y)
+        b, _, h, w = x.shape
+        x, y = x.detach().contiguous(), y.detach().contiguous()
+        out = torch.empty((b, 1, h, w), dtype=torch.float32, device=x.device)
+        lib, hp = L.lib(), model._head_params()
+        ws, wsn = _workspace(2 * b * h * w * 4 + 256, x.device)
+        L.check(lib.swf_final_head_fwd(C.byref(hp), _ptr(x), _ptr(y), _ptr(out), b, h, w, model.final_layer_conv_kernel_size, ws, wsn, _stream(x.device)))
+        return out
+
+    @staticmethod
+    def backward(ctx, gout):
+        model = ctx.model
+        x, y = ctx.saved_tensors
+        b, _, h, w = x.shape
+        dev = x.device
+        conv1, bn, conv2 = model.final_layer[0], model.final_layer[1], model.final_layer[3]
+        with torch.no_grad():
+            x, y, gout = x.contiguous(), y.contiguous(), gout.contiguous()
+            gx, gy = torch.empty_like(x), torch.empty_like(y)
+            new = lambda t: None if t is None else torch.empty(t.shape, dtype=torch.float32, device=dev)
+            g1w, g1b, gg, gb, g2w, g2b = new(conv1.weight), new(conv1.bias), new(bn.weight), new(bn.bias), new(conv2.weight), new(conv2.bias)
+            ptr = lambda t: None if t is None else t.data_ptr()
+            grads = L.HeadGrads(ptr(g1w), ptr(g1b), ptr(gg), ptr(gb), ptr(g2w), ptr(g2b))
+            lib, hp, ks = L.lib(), model._head_params(), model.final_layer_conv_kernel_size
+            ws, wsn = _workspace(lib.swf_final_head_bwd_workspace_bytes(b, h, w, ks), dev)
+            L.check(lib.swf_final_head_bwd(C.byref(hp), _ptr(x), _ptr(y), _ptr(gout), _ptr(gx), _ptr(gy), C.byref(grads), b, h, w, ks, ws, wsn, _stream(dev)))
+        return None, gx, gy, g1w, g1b, gg, gb, g2w, g2b
+
+
 def get_encoder_or_decoder_block(mode: str, window_size: tuple, feature_shape_recorder: StateRecorder,
                                  padding_size_recorder: StateRecorder, merging_size: tuple, in_dims: int, out_dims: int,
                                  patch_merging_size_recorder: StateRecorder, att_num_heads: int, att_dims_per_head: int,
@@ -1000,11 +1042,49 @@ class MyModel(_FwdAlias, nn.Module):
         self.load_state_dict(model_state, strict=True)
         return {k: v for k, v in state.items() if k != "model_state"} if isinstance(state, dict) else {}
 
+    def _head_params(self) -> L.HeadParams:
+        conv1, bn, conv2 = self.final_layer[0], self.final_layer[1], self.final_layer[3]
+        ptr = lambda t: None if t is None else _ptr(t)
+        return L.HeadParams(_ptr(conv1.weight), ptr(conv1.bias), _ptr(bn.weight), _ptr(bn.bias), _ptr(bn.running_mean), _ptr(bn.running_var),
+                            _ptr(conv2.weight), ptr(conv2.bias))
+
+    def _forward_autograd(self, in_x: Tensor, in_y: Tensor) -> Tensor:
+        """a013:209-230 module by module under torch.autograd (training side): every module's forward is a library
+        call and its backward a library call of kernels_bwd.hip (exact fp32).  eval() semantics: BatchNorm uses its running
+        statistics, dropout must be 0.  The one-call fused forward (swf_model_forward) is not differentiable and is not used here."""
+        if self.training:
+            raise RuntimeError("MyModel's autograd path has eval() semantics (BatchNorm running statistics, a013:133): batch-statistics "
+                               "BatchNorm is not implemented; call model.eval() and keep torch.enable_grad()")
+        if in_x.shape != in_y.shape or in_x.shape[1] != self.in_dims_list[0]:
+            raise ValueError(f"expected two (B,{self.in_dims_list[0]},H,W) tensors, got {tuple(in_x.shape)} and {tuple(in_y.shape)}")
+        self.u_net_intermediate_result_recorder.delete_all()
+        x, y = in_x, in_y
+        if not x.requires_grad:      # the module-level autograd Functions key on their inputs
+            x, y = x.detach().requires_grad_(True), y.detach().requires_grad_(True)
+        n = len(self.in_dims_list)
+        for j, stage in enumerate(self.encoder_list):          # a013:215-220
+            for mod in stage:
+                x, y = mod(x, y)
+            if j < n - 1:
+                self.u_net_intermediate_result_recorder.record((x, y))
+        for j, stage in enumerate(self.decoder_list):          # a013:221-227
+            if j > 0:
+                hx, hy = self.u_net_intermediate_result_recorder.read()
+                x, y = _AddFunction.apply(x, hx), _AddFunction.apply(y, hy)
+            for mod in stage:
+                x, y = mod(x, y)
+        conv1, bn, conv2 = self.final_layer[0], self.final_layer[1], self.final_layer[3]
+        return _HeadFunction.apply(self, x, y, conv1.weight, conv1.bias, bn.weight, bn.bias, conv2.weight, conv2.bias)
+
     # ---- forward ----------------------------------------------------------------------------------
     def forward(self, in_x: Tensor, in_y: Tensor) -> Tensor:
         """a013:209-230 as one C call.  The FIRST forward of a model (and every forward after a failed input check)
         reads the per-block identical-streams flags back to the host (a005:98-118), so it synchronises and cannot be
-        captured into a hipGraph: run one eager forward first (shard.ShardedFusion does)."""
+        captured into a hipGraph: run one eager forward first (shard.ShardedFusion does).
+        With torch.autograd recording (grad mode on and an input or parameter requiring grad) the forward runs module by module
+        instead and is differentiable (_forward_autograd)."""
+        if _wants_grad(self, in_x, in_y):
+            return self._forward_autograd(in_x, in_y)
         _check_forward_only(self, in_x, in_y)
         if self.training:
             raise RuntimeError("MyModel's HIP path is the eval() forward (BatchNorm running statistics, "

@@ -9,7 +9,8 @@ from torch import nn
 
 import __graft_entry__ as entry
 from oracle import swin_fusion_oracle as O
-from swin_unet_image_fusion_amd import BasicBlock, MyPadding, PatchMergingAndLinearLayer, StateRecorder, load_recipe_into
+from swin_unet_image_fusion_amd import (CONFIGS, BasicBlock, MyModel, MyPadding, PatchMergingAndLinearLayer, StateRecorder, load_recipe_into,
+                                        synthetic_pair)
 from tests import golden_util as G
 
 pytestmark = pytest.mark.gpu
@@ -137,3 +138,44 @@ def test_padding_backward_vs_autograd_of_the_oracle(win, shape):
     cx, _ = dec(gx * 2.0, gy)
     ((gx * wx.to(DEV)).sum() + (gy * wy.to(DEV)).sum() + cx.sum()).backward()
     assert torch.allclose(xg.grad.cpu(), x.grad, rtol=1e-5, atol=1e-6) and torch.allclose(yg.grad.cpu(), y.grad, rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("cfg_name,shape", [("tiny", (2, 16, 16)), ("tiny", (1, 18, 22)), ("tiny7", (1, 40, 36)), ("win8_4stage", (1, 128, 128))])
+def test_whole_model_backward_vs_autograd_of_the_oracle(cfg_name, shape):
+    """MyModel.forward under torch.autograd (module by module, a013:209-230; eval() semantics): dL/d(ir), dL/d(vis) and the gradient of
+    EVERY parameter of the model (all stages' blocks, patch layers with padding, skip adds, final head with BatchNorm affine) against
+    autograd of the oracle's model_forward; the loss is a generic linear functional plus an L1 term like the reference's (a008:226-282
+    mixes L1 / SSIM / gradient terms; kornia, which it needs, is absent here)."""
+    cfg = CONFIGS[cfg_name]
+    b, h, w = shape
+    m = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True))).eval()
+    load_recipe_into(m, seed=7, flavor="stress")
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in m.state_dict().items()}
+    ir, vis = (torch.from_numpy(a) for a in synthetic_pair(b, h, w, seed_ir=51, seed_vis=52))
+    ir.requires_grad_(True); vis.requires_grad_(True)
+    wgt, tgt = G.randn((b, 1, h, w), 851), G.randn((b, 1, h, w), 852) * 0.1
+    out = O.model_forward(sd, cfg, ir, vis)
+    ((out * wgt).sum() + (out - tgt).abs().sum()).backward()
+    m.to(DEV)
+    irg, visg = ir.detach().to(DEV).requires_grad_(True), vis.detach().to(DEV).requires_grad_(True)
+    outg = m(irg, visg)
+    assert outg.requires_grad
+    fwd_err = float((outg.detach().cpu() - out.detach()).abs().max() / out.detach().abs().max())
+    assert fwd_err <= 2e-3, fwd_err          # (the blocks' forward runs in the model's tier; the backward recomputes in exact fp32)
+    ((outg * wgt.to(DEV)).sum() + (outg - tgt.to(DEV)).abs().sum()).backward()
+
+    def rel(got, ref):
+        got, ref = got.detach().cpu().double(), ref.detach().double()
+        return float((got - ref).norm() / ref.norm().clamp_min(1e-30))
+
+    assert rel(irg.grad, ir.grad) <= 2e-3 and rel(visg.grad, vis.grad) <= 2e-3, (rel(irg.grad, ir.grad), rel(visg.grad, vis.grad))
+    worst, n_checked = 0.0, 0
+    gmax = max(float(v.grad.abs().max()) for v in sd.values() if v.requires_grad and v.grad is not None)
+    for k, p in m.named_parameters():
+        assert p.grad is not None, k
+        got, ref = p.grad.detach().cpu().double(), sd[k].grad.detach().double()
+        err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-3 * gmax)
+        worst = max(worst, err)
+        n_checked += 1
+    assert worst <= 5e-3, worst
+    assert n_checked == len(list(m.parameters()))
