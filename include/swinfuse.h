@@ -206,9 +206,18 @@ typedef struct swf_head_grads {
     float* conv1_w; float* conv1_b; float* bn_gamma; float* bn_beta; float* conv2_w; float* conv2_b;
 } swf_head_grads;
 size_t swf_final_head_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t ksize);
+/* batch_stats != 0: p->bn_mean / bn_var hold the BATCH statistics of this forward (training-mode BatchNorm, as the reference trains:
+ * a016:137 model.train()), and the normalisation's own gradient is included. */
 int swf_final_head_bwd(const swf_head_params* p, const float* x, const float* y, const float* gout, float* gx, float* gy,
-                       const swf_head_grads* gp, int32_t B, int32_t H, int32_t W, int32_t ksize,
+                       const swf_head_grads* gp, int32_t B, int32_t H, int32_t W, int32_t ksize, int32_t batch_stats,
                        void* workspace, size_t workspace_bytes, swf_stream_t stream);
+/* Training-mode BatchNorm2d of the head (a013:133 under model.train()): the batch mean and biased variance of conv1(cat(x, y)) per
+ * channel -> mean[2], var[2] (device; pass them as bn_mean / bn_var of swf_final_head_fwd / _bwd), and, when non-NULL,
+ * running = (1 - momentum) running + momentum (mean, unbiased variance) as nn.BatchNorm2d does.  Workspace: swf_final_head_bwd's. */
+int swf_final_head_batch_stats(const swf_head_params* p, const float* x, const float* y, float* mean, float* var,
+                               float* running_mean, float* running_var, float momentum,
+                               int32_t B, int32_t H, int32_t W, int32_t ksize,
+                               void* workspace, size_t workspace_bytes, swf_stream_t stream);
 
 /* ---- training side, second stage: patch layers, padding, skip add ------------------------------------------------------------ */
 /* Backward of one stream of PatchMergingAndLinearLayer (a011:244-264) as the module runs it (no padding inside: MyPadding is its own

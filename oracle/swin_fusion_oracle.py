@@ -222,14 +222,16 @@ def patch_layer(sd: State, prefix: str, x: Tensor, y: Tensor, *, encoder: bool,
     return outs[0], outs[1]
 
 
-def final_head(sd: State, x: Tensor, y: Tensor, ksize: int = 3) -> Tensor:
+def final_head(sd: State, x: Tensor, y: Tensor, ksize: int = 3, training: bool = False) -> Tensor:
     """MyModel.do_final_layer (a013_ModelDefinition.py:126-152): cat -> conv kxk (reflect
-    'same') -> BatchNorm2d eval -> ELU -> conv kxk (reflect 'same')."""
+    'same') -> BatchNorm2d -> ELU -> conv kxk (reflect 'same').  BatchNorm2d as nn.BatchNorm2d
+    runs it: running statistics under eval() (the inference path), batch statistics plus an
+    in-place running-statistics update (momentum 0.1) under train() (a016_train.py:137)."""
     p = ksize // 2
     z = torch.cat([x, y], dim=1)
     z = F.conv2d(F.pad(z, (p, p, p, p), mode="reflect"), sd["final_layer.0.weight"], sd["final_layer.0.bias"])
     z = F.batch_norm(z, sd["final_layer.1.running_mean"], sd["final_layer.1.running_var"],
-                     sd["final_layer.1.weight"], sd["final_layer.1.bias"], training=False, eps=1e-5)
+                     sd["final_layer.1.weight"], sd["final_layer.1.bias"], training=training, momentum=0.1, eps=1e-5)
     z = F.elu(z)
     return F.conv2d(F.pad(z, (p, p, p, p), mode="reflect"), sd["final_layer.3.weight"], sd["final_layer.3.bias"])
 
@@ -237,7 +239,7 @@ def final_head(sd: State, x: Tensor, y: Tensor, ksize: int = 3) -> Tensor:
 # ----------------------------------------------------------------------------------------
 # whole model
 # ----------------------------------------------------------------------------------------
-def model_forward(sd: State, cfg, in_x: Tensor, in_y: Tensor) -> Tensor:
+def model_forward(sd: State, cfg, in_x: Tensor, in_y: Tensor, training: bool = False) -> Tensor:
     """MyModel.forward (a013:209-230).  `cfg` is a FusionConfig-like object (window_size,
     merging_size, in_dims_list, out_dims_list, att_num_heads, att_dims_per_head_ratio,
     final_conv_layer_kernel_size).  Stage module order: encoder [pad2, merge, padW, blocks],
@@ -269,4 +271,4 @@ def model_forward(sd: State, cfg, in_x: Tensor, in_y: Tensor) -> Tensor:
         p = pads.pop(); x, y = crop_padding(x, p), crop_padding(y, p)
         x, y = patch_layer(sd, f"decoder_list.{j}.2.", x, y, encoder=False, merging_size=msz)
         p = pads.pop(); x, y = crop_padding(x, p), crop_padding(y, p)
-    return final_head(sd, x, y, cfg.final_conv_layer_kernel_size)
+    return final_head(sd, x, y, cfg.final_conv_layer_kernel_size, training=training)

@@ -94,7 +94,8 @@ SIGNATURES = {
     "swf_patch_layer_bwd": (C.c_int, [P(PatchParams), _vp, _vp, _vp, P(PatchParams), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_reflect_pad_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),
     "swf_final_head_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32]),
-    "swf_final_head_bwd": (C.c_int, [P(HeadParams), _vp, _vp, _vp, _vp, _vp, P(HeadGrads), _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_final_head_bwd": (C.c_int, [P(HeadParams), _vp, _vp, _vp, _vp, _vp, P(HeadGrads), _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_final_head_batch_stats": (C.c_int, [P(HeadParams), _vp, _vp, _vp, _vp, _vp, _vp, C.c_float, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_add_fwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "swf_block_pair4_fwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_patch_merge_fwd": (C.c_int, [P(PatchParams), _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),

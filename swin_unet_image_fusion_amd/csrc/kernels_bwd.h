@@ -19,6 +19,9 @@ int add_tensors(const float* a, const float* b, float* out, int64_t n, hipStream
 // final head (BatchNorm in eval mode)
 size_t head_bwd_ws(int B, int H, int W, int ks);
 int head_bwd(const swf_head_params& p, const float* x, const float* y, const float* gout, float* gx, float* gy, const swf_head_grads* gp, int B,
-             int H, int W, int ks, void* workspace, size_t workspace_bytes, hipStream_t stream);
+             int H, int W, int ks, int batch_stats, void* workspace, size_t workspace_bytes, hipStream_t stream);
+// batch mean / biased variance of conv1's two output channels (BatchNorm2d in training mode, a013:133) + the running-statistics update
+int head_batch_stats(const swf_head_params& p, const float* x, const float* y, float* mean, float* var, float* running_mean, float* running_var,
+                     float momentum, int B, int H, int W, int ks, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
 }  // namespace swf

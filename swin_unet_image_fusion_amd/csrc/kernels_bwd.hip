@@ -706,14 +706,19 @@ __global__ __launch_bounds__(256) void head_rows2_kernel(const float* __restrict
 
 // per-pixel rows for conv1 / BatchNorm gradients: [co][ci][ky][kx] dt1[co] in[ci](reflected source), dt1[0..1] (conv1 bias),
 // dt2[c] xhat[c] (gamma), dt2[c] (beta)
+// (BatchNorm in training mode normalises with the batch statistics, which depend on every t1: dt1 = a (dt2 - k1 - xhat k2) with
+//  k1 = mean(dt2), k2 = mean(dt2 xhat) per channel; eval mode: k1 = k2 = 0)
 __global__ __launch_bounds__(256) void head_rows1_kernel(const float* __restrict__ dt2, const float* __restrict__ t1, const float* __restrict__ x,
                                                           const float* __restrict__ y, float* __restrict__ rows, float a0, float a1, float m0,
-                                                          float m1, float is0, float is1, int B, int H, int W, int ks) {
+                                                          float m1, float is0, float is1, float k10, float k11, float k20, float k21,
+                                                          int B, int H, int W, int ks) {
     const int64_t total = (int64_t)B * H * W, e = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (e >= total) return;
     const int r = ks / 2, px = (int)(e % W), py = (int)((e / W) % H), NC = 4 * ks * ks + 6;
     const int64_t b = e / ((int64_t)W * H);
-    const float d0 = dt2[2 * e], d1 = dt2[2 * e + 1], g0 = d0 * a0, g1 = d1 * a1;   // dt1 = dt2 a
+    const float d0 = dt2[2 * e], d1 = dt2[2 * e + 1];
+    const float xh0 = (t1[2 * e] - m0) * is0, xh1 = (t1[2 * e + 1] - m1) * is1;
+    const float g0 = a0 * (d0 - k10 - xh0 * k20), g1 = a1 * (d1 - k11 - xh1 * k21);   // dt1
     float* row = rows + e * NC;
     for (int ky = 0; ky < ks; ++ky)
         for (int kx = 0; kx < ks; ++kx) {
@@ -725,13 +730,46 @@ __global__ __launch_bounds__(256) void head_rows1_kernel(const float* __restrict
             row[((1 * 2 + 1) * ks + ky) * ks + kx] = g1 * vy;
         }
     row[4 * ks * ks] = g0; row[4 * ks * ks + 1] = g1;
-    row[4 * ks * ks + 2] = d0 * (t1[2 * e] - m0) * is0; row[4 * ks * ks + 3] = d1 * (t1[2 * e + 1] - m1) * is1;
+    row[4 * ks * ks + 2] = d0 * xh0; row[4 * ks * ks + 3] = d1 * xh1;
     row[4 * ks * ks + 4] = d0; row[4 * ks * ks + 5] = d1;
 }
 
-__global__ __launch_bounds__(256) void head_scale2_kernel(const float* __restrict__ in, float* __restrict__ out, float a0, float a1, int64_t n) {
+// dt1 = a (dt2 - k1 - xhat k2) per channel
+__global__ __launch_bounds__(256) void head_dt1_kernel(const float* __restrict__ dt2, const float* __restrict__ t1, float* __restrict__ out, float a0,
+                                                        float a1, float m0, float m1, float is0, float is1, float k10, float k11, float k20,
+                                                        float k21, int64_t n) {
     const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    if (e < n) { out[2 * e] = in[2 * e] * a0; out[2 * e + 1] = in[2 * e + 1] * a1; }
+    if (e >= n) return;
+    out[2 * e] = a0 * (dt2[2 * e] - k10 - (t1[2 * e] - m0) * is0 * k20);
+    out[2 * e + 1] = a1 * (dt2[2 * e + 1] - k11 - (t1[2 * e + 1] - m1) * is1 * k21);
+}
+
+// rows [dt2_0 xhat_0, dt2_1 xhat_1, dt2_0, dt2_1]: their column means are k2, k1 of the training-mode BatchNorm backward
+__global__ __launch_bounds__(256) void head_rowsk_kernel(const float* __restrict__ dt2, const float* __restrict__ t1, float* __restrict__ rows, float m0,
+                                                          float m1, float is0, float is1, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    const float d0 = dt2[2 * e], d1 = dt2[2 * e + 1];
+    rows[4 * e] = d0 * (t1[2 * e] - m0) * is0; rows[4 * e + 1] = d1 * (t1[2 * e + 1] - m1) * is1; rows[4 * e + 2] = d0; rows[4 * e + 3] = d1;
+}
+
+// batch statistics of t1: pass 0 rows = t1, pass 1 rows = (t1 - mean)^2 with the mean read from `stat`
+__global__ __launch_bounds__(256) void head_stat_rows_kernel(const float* __restrict__ t1, const float* __restrict__ stat, float* __restrict__ rows,
+                                                              int pass, int64_t n) {
+    const int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (e >= n) return;
+    if (pass == 0) { rows[2 * e] = t1[2 * e]; rows[2 * e + 1] = t1[2 * e + 1]; }
+    else { const float d0 = t1[2 * e] - stat[0], d1 = t1[2 * e + 1] - stat[1]; rows[2 * e] = d0 * d0; rows[2 * e + 1] = d1 * d1; }
+}
+// sums -> mean (pass 0) or biased variance (pass 1); pass 1 also updates the running statistics (nn.BatchNorm2d: momentum, unbiased variance)
+__global__ void head_stat_finish_kernel(const float* __restrict__ sums, float* __restrict__ mean, float* __restrict__ var, float* __restrict__ rmean,
+                                        float* __restrict__ rvar, float momentum, int pass, float n) {
+    const int c = threadIdx.x;
+    if (c >= 2) return;
+    if (pass == 0) { mean[c] = sums[c] / n; return; }
+    var[c] = sums[c] / n;
+    if (rmean) rmean[c] = (1.0f - momentum) * rmean[c] + momentum * mean[c];
+    if (rvar) rvar[c] = (1.0f - momentum) * rvar[c] + momentum * (n > 1.0f ? sums[c] / (n - 1.0f) : var[c]);
 }
 
 __global__ __launch_bounds__(256) void head_split_kernel(const float* __restrict__ g2, float* __restrict__ gx, float* __restrict__ gy, int64_t n) {
@@ -746,8 +784,35 @@ size_t head_bwd_ws(int B, int H, int W, int ks) {
     return carve_bytes({2 * n, 2 * n, 2 * n, n * nc, (int64_t)chunks_of(n) * nc + nc + 64});
 }
 
+int head_batch_stats(const swf_head_params& p, const float* x, const float* y, float* mean, float* var, float* running_mean, float* running_var,
+                     float momentum, int B, int H, int W, int ks, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (ks < 1 || ks % 2 == 0 || ks / 2 >= H || ks / 2 >= W) return fail(SWF_ERR_PAD, "head statistics: kernel %d on a %dx%d map", ks, H, W);
+    const int64_t n = (int64_t)B * H * W;
+    Carver ws(workspace, workspace_bytes);
+    float* t1 = ws.floats(2 * n);
+    float* rows = ws.floats(2 * n);
+    float* part = ws.floats((int64_t)chunks_of(n) * 2 + 64);
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "head statistics workspace too small (need %zu B)", ws.used);
+    const unsigned blocks = (unsigned)cdiv64(n, 256);
+    const int ch = chunks_of(n);
+    float* sums = part + (int64_t)ch * 2;
+    hipLaunchKernelGGL(head_t1_kernel, dim3(blocks), dim3(256), 0, st, x, y, t1, p, B, H, W, ks);
+    SWF_TRY(check_launch("head_t1"));
+    for (int pass = 0; pass < 2; ++pass) {
+        hipLaunchKernelGGL(head_stat_rows_kernel, dim3(blocks), dim3(256), 0, st, t1, mean, rows, pass, n);
+        SWF_TRY(check_launch("head stat rows"));
+        hipLaunchKernelGGL(bwd_colsum_kernel, dim3(1, ch), dim3(256), 0, st, rows, part, (int)n, 2);
+        SWF_TRY(check_launch("head stat colsum"));
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, part, sums, (int64_t)2, ch);
+        SWF_TRY(check_launch("head stat reduce"));
+        hipLaunchKernelGGL(head_stat_finish_kernel, dim3(1), dim3(64), 0, st, sums, mean, var, running_mean, running_var, momentum, pass, (float)n);
+        SWF_TRY(check_launch("head stat finish"));
+    }
+    return SWF_OK;
+}
+
 int head_bwd(const swf_head_params& p, const float* x, const float* y, const float* gout, float* gx, float* gy, const swf_head_grads* gp, int B,
-             int H, int W, int ks, void* workspace, size_t workspace_bytes, hipStream_t st) {
+             int H, int W, int ks, int batch_stats, void* workspace, size_t workspace_bytes, hipStream_t st) {
     if (ks < 1 || ks % 2 == 0 || ks / 2 >= H || ks / 2 >= W) return fail(SWF_ERR_PAD, "head backward: kernel %d on a %dx%d map", ks, H, W);
     const int64_t n = (int64_t)B * H * W;
     const int nc1 = 4 * ks * ks + 6, nc2 = 2 * ks * ks + 1;
@@ -793,7 +858,18 @@ int head_bwd(const swf_head_params& p, const float* x, const float* y, const flo
         SWF_TRY(copy(g.conv2_w, sums, 2 * ks * ks));
         SWF_TRY(copy(g.conv2_b, sums + 2 * ks * ks, 1));
     }
-    hipLaunchKernelGGL(head_rows1_kernel, dim3(blocks), dim3(256), 0, st, dt2, t1, x, y, rows, a[0], a[1], hm[0], hm[1], is[0], is[1], B, H, W, ks);
+    float k1[2] = {0.f, 0.f}, k2[2] = {0.f, 0.f};
+    if (batch_stats) {   // p.bn_mean / p.bn_var hold the BATCH statistics of this forward: the normalisation itself has a gradient
+        hipLaunchKernelGGL(head_rowsk_kernel, dim3(blocks), dim3(256), 0, st, dt2, t1, rows, hm[0], hm[1], is[0], is[1], n);
+        SWF_TRY(check_launch("head rows k"));
+        SWF_TRY(colsums(4, sums));
+        float hs[4];
+        if (hipMemcpyAsync(hs, sums, 16, hipMemcpyDeviceToHost, st) != hipSuccess || hipStreamSynchronize(st) != hipSuccess)
+            return fail(SWF_ERR_HIP, "head backward: reading the batch sums failed");
+        for (int i = 0; i < 2; ++i) { k2[i] = hs[i] / (float)n; k1[i] = hs[2 + i] / (float)n; }
+    }
+    hipLaunchKernelGGL(head_rows1_kernel, dim3(blocks), dim3(256), 0, st, dt2, t1, x, y, rows, a[0], a[1], hm[0], hm[1], is[0], is[1], k1[0], k1[1],
+                       k2[0], k2[1], B, H, W, ks);
     SWF_TRY(check_launch("head rows1"));
     SWF_TRY(colsums(nc1, sums));
     SWF_TRY(copy(g.conv1_w, sums, 4 * ks * ks));
@@ -806,7 +882,8 @@ int head_bwd(const swf_head_params& p, const float* x, const float* y, const flo
         // scale channel c of dt2 by a[c] with the split kernel's twin: reuse head_conv_adjoint's generic form on pre-scaled gradients
         // through rows as scratch: rows[e*2+c] = dt2[e*2+c] * a[c]
         float* dt1 = rows;
-        hipLaunchKernelGGL(head_scale2_kernel, dim3(blocks), dim3(256), 0, st, dt2, dt1, a[0], a[1], n);
+        hipLaunchKernelGGL(head_dt1_kernel, dim3(blocks), dim3(256), 0, st, dt2, t1, dt1, a[0], a[1], hm[0], hm[1], is[0], is[1], k1[0], k1[1], k2[0],
+                           k2[1], n);
         SWF_TRY(check_launch("head dt1"));
         hipLaunchKernelGGL(head_conv_adjoint_kernel, dim3(blocks), dim3(256), 0, st, dt1, p.conv1_w, din, 2, t1, 0.f, 0.f, 0.f, 0.f, 0, B, H, W, ks);
         SWF_TRY(check_launch("head adjoint conv1"));

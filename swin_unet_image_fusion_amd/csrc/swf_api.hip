@@ -1215,12 +1215,21 @@ size_t swf_final_head_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32
     return head_bwd_ws(B, H, W, ksize);
 }
 
+int swf_final_head_batch_stats(const swf_head_params* p, const float* x, const float* y, float* mean, float* var, float* running_mean,
+                               float* running_var, float momentum, int32_t B, int32_t H, int32_t W, int32_t ksize, void* workspace,
+                               size_t workspace_bytes, swf_stream_t stream) {
+    if (!p || !p->conv1_w || !x || !y || !mean || !var) return fail(SWF_ERR_NULL, "final_head_batch_stats: NULL argument");
+    if (B <= 0 || H <= 0 || W <= 0) return fail(SWF_ERR_BAD_SHAPE, "final_head_batch_stats: empty tensor");
+    return head_batch_stats(*p, x, y, mean, var, running_mean, running_var, momentum, B, H, W, ksize, workspace, workspace_bytes, as_stream(stream));
+}
+
 int swf_final_head_bwd(const swf_head_params* p, const float* x, const float* y, const float* gout, float* gx, float* gy, const swf_head_grads* gp,
-                       int32_t B, int32_t H, int32_t W, int32_t ksize, void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+                       int32_t B, int32_t H, int32_t W, int32_t ksize, int32_t batch_stats, void* workspace, size_t workspace_bytes,
+                       swf_stream_t stream) {
     if (!p || !p->conv1_w || !p->conv2_w || !p->bn_gamma || !p->bn_beta || !p->bn_mean || !p->bn_var || !x || !y || !gout || !gx || !gy)
         return fail(SWF_ERR_NULL, "final_head_bwd: NULL argument");
     if (B <= 0 || H <= 0 || W <= 0) return fail(SWF_ERR_BAD_SHAPE, "final_head_bwd: empty tensor");
-    return head_bwd(*p, x, y, gout, gx, gy, gp, B, H, W, ksize, workspace, workspace_bytes, as_stream(stream));
+    return head_bwd(*p, x, y, gout, gx, gy, gp, B, H, W, ksize, batch_stats, workspace, workspace_bytes, as_stream(stream));
 }
 
 int swf_add_fwd(const float* a, const float* b, float* out, int64_t count, swf_stream_t stream) {

@@ -830,24 +830,37 @@ class PatchMergingAndLinearLayer(_FwdAlias, nn.Module):
 # a013: model assembly
 # ----------------------------------------------------------------------------------------------
 class _HeadFunction(torch.autograd.Function):
-    """MyModel.do_final_layer (a013:126-152) under autograd, BatchNorm in eval mode: forward swf_final_head_fwd, backward swf_final_head_bwd."""
+    """MyModel.do_final_layer (a013:126-152) under autograd: forward swf_final_head_fwd (after swf_final_head_batch_stats in training
+    mode), backward swf_final_head_bwd."""
 
     @staticmethod
     def forward(ctx, model, x, y, c1w, c1b, g, bt, c2w, c2b):
-        ctx.model = model
-        ctx.save_for_backward(x, y)
+        ctx.model, ctx.train = model, bool(model.training)
         b, _, h, w = x.shape
         x, y = x.detach().contiguous(), y.detach().contiguous()
         out = torch.empty((b, 1, h, w), dtype=torch.float32, device=x.device)
-        lib, hp = L.lib(), model._head_params()
-        ws, wsn = _workspace(2 * b * h * w * 4 + 256, x.device)
-        L.check(lib.swf_final_head_fwd(C.byref(hp), _ptr(x), _ptr(y), _ptr(out), b, h, w, model.final_layer_conv_kernel_size, ws, wsn, _stream(x.device)))
+        lib, hp, ks = L.lib(), model._head_params(), model.final_layer_conv_kernel_size
+        ws, wsn = _workspace(lib.swf_final_head_bwd_workspace_bytes(b, h, w, ks), x.device)
+        stats = torch.empty(4, dtype=torch.float32, device=x.device)   # batch mean[2], biased variance[2]
+        if ctx.train:
+            # nn.BatchNorm2d in training mode (the reference trains under model.train(), a016:137): normalise with the batch statistics
+            # of this forward and move the running statistics towards them (momentum 0.1, unbiased variance)
+            bn = model.final_layer[1]
+            mom = 0.1 if bn.momentum is None else float(bn.momentum)
+            L.check(lib.swf_final_head_batch_stats(C.byref(hp), _ptr(x), _ptr(y), stats.data_ptr(), stats.data_ptr() + 8,
+                                                   _ptr(bn.running_mean) if bn.track_running_stats else None,
+                                                   _ptr(bn.running_var) if bn.track_running_stats else None, mom, b, h, w, ks, ws, wsn, _stream(x.device)))
+            if bn.track_running_stats and bn.num_batches_tracked is not None:
+                bn.num_batches_tracked += 1
+            hp.bn_mean, hp.bn_var = stats.data_ptr(), stats.data_ptr() + 8
+        ctx.save_for_backward(x, y, stats)
+        L.check(lib.swf_final_head_fwd(C.byref(hp), _ptr(x), _ptr(y), _ptr(out), b, h, w, ks, ws, wsn, _stream(x.device)))
         return out
 
     @staticmethod
     def backward(ctx, gout):
         model = ctx.model
-        x, y = ctx.saved_tensors
+        x, y, stats = ctx.saved_tensors
         b, _, h, w = x.shape
         dev = x.device
         conv1, bn, conv2 = model.final_layer[0], model.final_layer[1], model.final_layer[3]
@@ -859,8 +872,11 @@ class _HeadFunction(torch.autograd.Function):
             ptr = lambda t: None if t is None else t.data_ptr()
             grads = L.HeadGrads(ptr(g1w), ptr(g1b), ptr(gg), ptr(gb), ptr(g2w), ptr(g2b))
             lib, hp, ks = L.lib(), model._head_params(), model.final_layer_conv_kernel_size
+            if ctx.train:
+                hp.bn_mean, hp.bn_var = stats.data_ptr(), stats.data_ptr() + 8
             ws, wsn = _workspace(lib.swf_final_head_bwd_workspace_bytes(b, h, w, ks), dev)
-            L.check(lib.swf_final_head_bwd(C.byref(hp), _ptr(x), _ptr(y), _ptr(gout), _ptr(gx), _ptr(gy), C.byref(grads), b, h, w, ks, ws, wsn, _stream(dev)))
+            L.check(lib.swf_final_head_bwd(C.byref(hp), _ptr(x), _ptr(y), _ptr(gout), _ptr(gx), _ptr(gy), C.byref(grads), b, h, w, ks,
+                                           int(ctx.train), ws, wsn, _stream(dev)))
         return None, gx, gy, g1w, g1b, gg, gb, g2w, g2b
 
 
@@ -1050,11 +1066,10 @@ class MyModel(_FwdAlias, nn.Module):
 
     def _forward_autograd(self, in_x: Tensor, in_y: Tensor) -> Tensor:
         """a013:209-230 module by module under torch.autograd (training side): every module's forward is a library
-        call and its backward a library call of kernels_bwd.hip (exact fp32).  eval() semantics: BatchNorm uses its running
-        statistics, dropout must be 0.  The one-call fused forward (swf_model_forward) is not differentiable and is not used here."""
-        if self.training:
-            raise RuntimeError("MyModel's autograd path has eval() semantics (BatchNorm running statistics, a013:133): batch-statistics "
-                               "BatchNorm is not implemented; call model.eval() and keep torch.enable_grad()")
+        call and its backward a library call of kernels_bwd.hip (exact fp32).  Both modes of the reference: under model.train() the
+        head's BatchNorm normalises with the batch statistics and updates its running statistics (a016:137), under model.eval() it uses
+        the running statistics; dropout must be 0 (the reference's configuration, A000_CONFIG.py).  The one-call fused forward
+        (swf_model_forward) is not differentiable and is not used here."""
         if in_x.shape != in_y.shape or in_x.shape[1] != self.in_dims_list[0]:
             raise ValueError(f"expected two (B,{self.in_dims_list[0]},H,W) tensors, got {tuple(in_x.shape)} and {tuple(in_y.shape)}")
         self.u_net_intermediate_result_recorder.delete_all()
@@ -1073,6 +1088,11 @@ class MyModel(_FwdAlias, nn.Module):
                 x, y = _AddFunction.apply(x, hx), _AddFunction.apply(y, hy)
             for mod in stage:
                 x, y = mod(x, y)
+        return self.do_final_layer(x, y)
+
+    def do_final_layer(self, x: Tensor, y: Tensor) -> Tensor:
+        """a013:126-152 on its own: cat -> conv -> BatchNorm2d (batch statistics under train(), running statistics under eval()) ->
+        ELU -> conv, differentiable."""
         conv1, bn, conv2 = self.final_layer[0], self.final_layer[1], self.final_layer[3]
         return _HeadFunction.apply(self, x, y, conv1.weight, conv1.bias, bn.weight, bn.bias, conv2.weight, conv2.bias)
 

@@ -179,3 +179,68 @@ def test_whole_model_backward_vs_autograd_of_the_oracle(cfg_name, shape):
         n_checked += 1
     assert worst <= 5e-3, worst
     assert n_checked == len(list(m.parameters()))
+
+
+@pytest.mark.parametrize("cfg_name,shape", [("tiny", (3, 16, 16)), ("tiny7", (2, 30, 26)), ("win8_4stage", (2, 128, 128))])
+def test_training_mode_steps_vs_autograd_of_the_oracle(cfg_name, shape):
+    """model.train() as the reference trains (a016:137): the head's BatchNorm2d normalises with the batch statistics (whose gradient
+    flows back into conv1 and the decoder), and its running statistics move by momentum 0.1 with the unbiased variance.  Three plain
+    SGD steps on the GPU model against three steps of autograd on the oracle from the same start: output, every gradient of the first
+    step, the running statistics and the weights after the last step."""
+    cfg = CONFIGS[cfg_name]
+    b, h, w = shape
+    m = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True)))
+    load_recipe_into(m, seed=11, flavor="stress")
+    sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in m.state_dict().items()}
+    m.to(DEV).train()
+    lr, first = 1e-3, None
+    for step in range(3):
+        ir, vis = (torch.from_numpy(a) for a in synthetic_pair(b, h, w, seed_ir=61 + step, seed_vis=71 + step))
+        tgt = torch.maximum(ir, vis)
+        for v in sd.values():
+            v.grad = None
+        out = O.model_forward(sd, cfg, ir, vis, training=True)
+        (out - tgt).square().mean().backward()     # (smooth: an L1 term flips sign where the two forwards straddle the target)
+        m.zero_grad(set_to_none=True)
+        outg = m(ir.to(DEV), vis.to(DEV))
+        (outg - tgt.to(DEV)).square().mean().backward()
+        assert float((outg.detach().cpu() - out.detach()).abs().max() / out.detach().abs().max()) <= 2e-3
+        if step == 0:
+            gmax = max(float(v.grad.abs().max()) for v in sd.values() if v.requires_grad and v.grad is not None)
+            first = max(float((p.grad.cpu().double() - sd[k].grad.double()).abs().max()) / max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
+                        for k, p in m.named_parameters())
+            assert first <= 5e-3, first
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                p -= lr * p.grad
+                sd[k] -= lr * sd[k].grad
+    got = m.state_dict()
+    for k in ("final_layer.1.running_mean", "final_layer.1.running_var"):
+        assert torch.allclose(got[k].cpu(), sd[k], rtol=2e-3, atol=1e-6), (k, got[k].cpu(), sd[k])
+    assert int(got["final_layer.1.num_batches_tracked"]) == 3
+    for k, p in m.named_parameters():
+        ref = sd[k].detach()
+        assert float((p.detach().cpu() - ref).abs().max()) <= 1e-3 * lr * max(gmax, 1.0) + 1e-5 * float(ref.abs().max()), k
+
+
+def test_head_batch_statistics_match_torch():
+    """swf_final_head_batch_stats alone: mean / biased variance of conv1's output and the running-statistics update, against
+    F.batch_norm(training=True) on the oracle's conv1."""
+    import torch.nn.functional as F
+    cfg = CONFIGS["tiny"]
+    m = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True)))
+    load_recipe_into(m, seed=3, flavor="stress")
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x, y = G.randn((2, 1, 11, 9), 901), G.randn((2, 1, 11, 9), 902)
+    z = F.conv2d(F.pad(torch.cat([x, y], 1), (1, 1, 1, 1), mode="reflect"), sd["final_layer.0.weight"], sd["final_layer.0.bias"])
+    mean, var = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
+    rm, rv = sd["final_layer.1.running_mean"].clone(), sd["final_layer.1.running_var"].clone()
+    F.batch_norm(z, rm, rv, None, None, training=True, momentum=0.1)
+    m.to(DEV).train()
+    xg, yg = x.to(DEV).requires_grad_(True), y.to(DEV).requires_grad_(True)
+    out = m.do_final_layer(xg, yg)
+    ref = O.final_head(sd, x, y, 3, training=True)
+    assert torch.allclose(out.detach().cpu(), ref, rtol=1e-4, atol=1e-5)
+    bn = m.final_layer[1]
+    assert torch.allclose(bn.running_mean.cpu(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(bn.running_var.cpu(), rv, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_mean.cpu(), 0.9 * sd["final_layer.1.running_mean"] + 0.1 * mean, rtol=1e-5, atol=1e-6)
