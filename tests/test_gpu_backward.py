@@ -235,6 +235,7 @@ def test_head_batch_statistics_match_torch():
     z = F.conv2d(F.pad(torch.cat([x, y], 1), (1, 1, 1, 1), mode="reflect"), sd["final_layer.0.weight"], sd["final_layer.0.bias"])
     mean, var = z.mean((0, 2, 3)), z.var((0, 2, 3), unbiased=False)
     rm, rv = sd["final_layer.1.running_mean"].clone(), sd["final_layer.1.running_var"].clone()
+    rm0 = rm.clone()
     F.batch_norm(z, rm, rv, None, None, training=True, momentum=0.1)
     m.to(DEV).train()
     xg, yg = x.to(DEV).requires_grad_(True), y.to(DEV).requires_grad_(True)
@@ -243,4 +244,4 @@ def test_head_batch_statistics_match_torch():
     assert torch.allclose(out.detach().cpu(), ref, rtol=1e-4, atol=1e-5)
     bn = m.final_layer[1]
     assert torch.allclose(bn.running_mean.cpu(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(bn.running_var.cpu(), rv, rtol=1e-5, atol=1e-6)
-    assert torch.allclose(bn.running_mean.cpu(), 0.9 * sd["final_layer.1.running_mean"] + 0.1 * mean, rtol=1e-5, atol=1e-6)
+    assert torch.allclose(bn.running_mean.cpu(), 0.9 * rm0 + 0.1 * mean, rtol=1e-5, atol=1e-6)
