@@ -45,6 +45,7 @@ def parse():
     ap.add_argument("--config", default="win8")
     ap.add_argument("--precision", default="fast", choices=["fast", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
+    ap.add_argument("--in-flight", type=int, default=2, help="steps kept in flight per GPU (hipGraph lanes on separate streams; 1 = one chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs per CPU-baseline forward")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -322,29 +323,32 @@ def main():
         load_recipe_into(model, seed=0, flavor="default")     # random-init weights of the named architecture
         model.to(dev)
         model.precision = args.precision
-        runner = ShardedFusion(model, world_size=world, rank=rank, use_graph=not args.no_graph)
+        runner = ShardedFusion(model, world_size=world, rank=rank, use_graph=not args.no_graph,
+                               in_flight=1 if args.no_graph else args.in_flight)
 
     # synthetic IR / visible pairs, distinct per rank, resident in HBM before the timed region
     hh, ww_ = args.height or args.size, args.width or args.size
     ir, vis = synthetic_pair(args.batch, hh, ww_, seed_ir=1 + 2 * rank, seed_vis=2 + 2 * rank)
     ir, vis = torch.from_numpy(ir).to(dev), torch.from_numpy(vis).to(dev)
 
-    for _ in range(max(args.warmup, 1)):
+    for _ in range(max(args.warmup, 1, 0 if dry else runner.in_flight)):   # (every lane of the runner captures and runs once)
         fused = runner.step(ir, vis)
     sync()
     if world > 1:
         dist.barrier()
     sync()
     t0 = time.perf_counter()
-    # every step = forward of the local shard + all-gather of the fused outputs; the gather of step i runs on RCCL's stream under
-    # the forward of step i+1 and is waited for (stream-level) one step later; all K gathers have completed at the final sync
-    pending = None
+    # every step = forward of the local shard + all-gather of the fused outputs.  Steps are independent batches and the runner keeps
+    # `in_flight` of them going: step i+1 is enqueued (its own hipGraph, buffers and stream) before step i is waited for, so its wide
+    # level-0 launches run under the latency-bound deep levels of step i, and the gather of step i runs on RCCL's stream under both.
+    # Every step is waited for (stream-level) in order; all K forwards and gathers have completed at the final sync.
+    pending = []
     for _ in range(args.steps):
-        handle = runner.step_async(ir, vis)
-        if pending is not None:
-            fused = pending.wait()
-        pending = handle
-    fused = pending.wait()
+        pending.append(runner.step_async(ir, vis))
+        if len(pending) >= max(runner.in_flight, 2):
+            fused = pending.pop(0).wait()
+    while pending:
+        fused = pending.pop(0).wait()
     sync()
     if world > 1:
         dist.barrier()
@@ -355,6 +359,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     assert fused.shape[0] == args.batch * world and bool(torch.isfinite(fused).all())
+    # the same steps one at a time (each waited for before the next is enqueued): the latency of one step, for the record
+    serial_ms = None
+    if not dry and runner.in_flight > 1:
+        n_serial = min(args.steps, 20)
+        sync()
+        t1 = time.perf_counter()
+        for _ in range(n_serial):
+            fused = runner.step(ir, vis)
+        sync()
+        serial_ms = (time.perf_counter() - t1) / n_serial * 1e3
     # the timed path is the hipGraph replay: check it against one eager forward of the same inputs before reporting it
     graph_equals_eager = None
     if runner.graph_active:
@@ -374,6 +388,9 @@ def main():
                        "arithmetic": "linear layers split-bf16 (bf16x3) MFMA, QK^T and P.V fp16 MFMA (fp32 accumulate), everything else fp32"
                                      if args.precision == "fast" else "exact fp32 (f32-input MFMA)",
                        "residual_stream": "fp32", "hip_graph": runner.graph_active, "graph_equals_eager": graph_equals_eager,
+                       "steps_in_flight": runner.in_flight if runner.graph_active else 1,
+                       "one_step_at_a_time": None if serial_ms is None else
+                       {"ms_per_step": round(serial_ms, 4), "pairs_per_s": round(args.batch * world / serial_ms * 1e3, 1)},
                        "collective": "rccl all_gather_into_tensor of the fused output per step, overlapped with the next step's forward" if world > 1 else "none",
                        "weights": "random-init (numpy PCG64 recipe, seed 0)"},
         }

@@ -27,17 +27,29 @@ def shard_bounds(batch: int, world_size: int, rank: int) -> Tuple[int, int, int]
 
 
 class GatherHandle:
-    """Result of ShardedFusion.step_async(): wait() returns the gathered tensor once the collective is ordered before the
-    caller's stream (GPU: a stream-level wait, the host does not block; gloo: a host wait)."""
+    """Result of ShardedFusion.step_async(): wait() returns the gathered tensor once the step (and its collective) is ordered before
+    the caller's stream (GPU: a stream-level wait, the host does not block; gloo: a host wait)."""
 
-    def __init__(self, tensor: torch.Tensor, work=None):
-        self._tensor, self._work = tensor, work
+    def __init__(self, tensor: torch.Tensor, work=None, event=None):
+        self._tensor, self._work, self._event = tensor, work, event
 
     def wait(self) -> torch.Tensor:
         if self._work is not None:
             self._work.wait()
             self._work = None
+        if self._event is not None:
+            torch.cuda.current_stream(self._tensor.device).wait_event(self._event)
+            self._event = None
         return self._tensor
+
+
+class _Lane:
+    """One captured forward: the hipGraph, the runner-owned static input / output buffers it was captured on, the key it was captured
+    for, its capture stream (also the stream it replays on when steps overlap) and the library workspace it points into."""
+    __slots__ = ("graph", "static", "key", "stream", "ws_ref")
+
+    def __init__(self):
+        self.graph = self.static = self.key = self.stream = self.ws_ref = None
 
 
 class ShardedFusion:
@@ -45,12 +57,19 @@ class ShardedFusion:
 
     step_async(ir, vis) returns a GatherHandle instead: the all-gather runs on the process group's own stream (RCCL over
     xGMI) while the caller enqueues the NEXT step's forward, and only handle.wait() orders it before the caller's stream.
-    The local output is first copied into one of two staging buffers (the captured graph rewrites its output buffer at
-    the next replay) and gathered into one of two result buffers, so a handle stays valid until the second step after it.
+    The local output is first copied into a staging buffer (the captured graph rewrites its output buffer at its next replay)
+    and gathered into a result buffer of a small ring, so a handle stays valid until `in_flight` + 1 steps after it.
 
     forward_fn defaults to `model(ir, vis)` (the HIP path).  With `use_graph` the forward is captured
     into a hipGraph (torch.cuda.CUDAGraph on ROCm) and replayed: ~100 kernel launches per forward
     collapse into one graph launch.  The collective stays outside the graph.
+
+    in_flight > 1 (graph mode on a GPU only): that many captured copies of the forward ("lanes"), each with its own static buffers,
+    workspace and stream; consecutive step_async() calls go to consecutive lanes and run CONCURRENTLY until their handles are
+    waited for.  One forward is a chain of ~90 dependent launches whose deep levels occupy a fraction of the chip for their latency
+    (DESIGN 5): a second step in flight runs its wide level-0 launches under them.  Steps are independent batches, so results do
+    not change; a lane's output buffer is rewritten `in_flight` steps later.  step() / local_forward() wait at once and so stay
+    serial.
 
     A captured graph bakes in raw addresses: the model's weight arena and packed images, the library
     workspace, the arithmetic mode and the static input / output buffers.  It is therefore keyed on
@@ -58,40 +77,48 @@ class ShardedFusion:
     refresh_weights(), .to() or `model.precision = ...` the next step runs the new weights (a017:50-54: load,
     then infer).  The static input buffers belong to the runner (callers' tensors are copied in, never
     adopted), and the tensor returned by local_forward()/step() at world_size 1 is the runner's static
-    output buffer: it is overwritten by the next step — clone it to keep it."""
+    output buffer: it is overwritten by a later step — clone it to keep it."""
 
     def __init__(self, model=None, world_size: int = 1, rank: int = 0, use_graph: bool = False,
-                 forward_fn: Optional[Callable] = None, group=None, force_collective: bool = False):
+                 forward_fn: Optional[Callable] = None, group=None, force_collective: bool = False, in_flight: int = 1):
         # force_collective: issue the all-gather even at world_size 1 (a one-rank RCCL group exercises the GPU branch on a
         # single-GPU box: tests/test_gpu_parity.py)
+        if in_flight < 1:
+            raise ValueError(f"in_flight must be >= 1, got {in_flight}")
         self.model, self.world_size, self.rank, self.group = model, world_size, rank, group
         self.force_collective = force_collective
         self.forward_fn = forward_fn or (lambda a, b: model(a, b))
         self.use_graph = use_graph
+        self.in_flight = in_flight
         self.graph_active = False
-        self._graph = None
-        self._static = None   # (ir, vis, out) of the captured graph
-        self._key = None      # (input shape, model.graph_key()) the graph was captured for
-        self._gathered = [None, None]   # double-buffered: step i+1 may run while step i's result is still being gathered / read
-        self._stage = [None, None]
+        self._lanes = [_Lane() for _ in range(in_flight)]
+        self._turn = 0
+        nslots = in_flight + 1   # step i+1 .. i+in_flight may run while step i's result is still being gathered / read
+        self._gathered = [None] * nslots
+        self._stage = [None] * nslots
+        self._slot_work = [None] * nslots
         self._slot = 0
-        self._cap_stream = None   # one capture stream for the runner's lifetime: the library workspace is keyed by stream
-        self._ws_ref = None       # the library workspace the captured graph points into: held so that nothing frees it
         self.captures = 0
+
+    # (the first lane under its old names: tests and tools look at them)
+    _graph = property(lambda self: self._lanes[0].graph)
+    _static = property(lambda self: self._lanes[0].static)
+    _ws_ref = property(lambda self: self._lanes[0].ws_ref)
+    _cap_stream = property(lambda self: self._lanes[0].stream)
 
     # -- forward of the local shard --------------------------------------------------------------
     def _model_key(self):
         return self.model.graph_key() if hasattr(self.model, "graph_key") else None
 
-    def _capture(self, ir, vis):
+    def _capture(self, lane: _Lane, ir, vis):
         ir, vis = ir.clone(), vis.clone()             # runner-owned static buffers
-        self._graph = self._static = self._ws_ref = None   # drop the old graph before its buffers
+        lane.graph = lane.static = lane.ws_ref = None      # drop the old graph before its buffers
         self.forward_fn(ir, vis)                      # warm-up: sizes the workspace, builds the arena, first-forward check
         torch.cuda.synchronize()
         g = torch.cuda.CUDAGraph()
-        if self._cap_stream is None:
-            self._cap_stream = torch.cuda.Stream(device=ir.device)
-        s = self._cap_stream
+        if lane.stream is None:                       # one capture stream for the lane's lifetime: the library workspace is keyed by stream
+            lane.stream = torch.cuda.Stream(device=ir.device)
+        s = lane.stream
         s.wait_stream(torch.cuda.current_stream(ir.device))
         with torch.cuda.stream(s):
             self.forward_fn(ir, vis)                  # warm-up on the capture stream (its own workspace)
@@ -106,46 +133,82 @@ class ShardedFusion:
         # Holding the tensor keeps the captured address valid for as long as this graph exists.
         try:
             from .modules import _workspace_tensor
-            self._ws_ref = _workspace_tensor(ir.device, s.cuda_stream)
+            lane.ws_ref = _workspace_tensor(ir.device, s.cuda_stream)
         except ImportError:       # forward_fn-only runners (tests on CPU) never get here: capture needs CUDA tensors
-            self._ws_ref = None
-        self._graph, self._static, self.graph_active = g, (ir, vis, out), True
-        self._key = (tuple(ir.shape), self._model_key())   # after the capture: the arena / packed images exist now
+            lane.ws_ref = None
+        lane.graph, lane.static, self.graph_active = g, (ir, vis, out), True
+        lane.key = (tuple(ir.shape), self._model_key())   # after the capture: the arena / packed images exist now
         self.captures += 1
+
+    def _ready_lane(self, lane: _Lane, ir, vis) -> _Lane:
+        if lane.static is None or lane.key != (tuple(ir.shape), self._model_key()):
+            self._capture(lane, ir, vis)
+        return lane
+
+    def _issue(self, ir, vis) -> _Lane:
+        """Next lane in turn: inputs copied in and the graph replayed on the LANE's stream, after everything the caller's stream holds
+        so far (input producers; consumers of this lane's previous output).  Nothing waits for it here."""
+        lane = self._ready_lane(self._lanes[self._turn], ir, vis)
+        self._turn = (self._turn + 1) % self.in_flight
+        s_ir, s_vis, _ = lane.static
+        lane.stream.wait_stream(torch.cuda.current_stream(ir.device))
+        with torch.cuda.stream(lane.stream):
+            s_ir.copy_(ir)
+            s_vis.copy_(vis)
+            lane.graph.replay()
+        ir.record_stream(lane.stream)
+        vis.record_stream(lane.stream)
+        return lane
+
+    def _overlapped(self, ir) -> bool:
+        return self.in_flight > 1 and self.use_graph and ir.is_cuda
 
     def local_forward(self, ir, vis):
         if not (self.use_graph and ir.is_cuda):
             return self.forward_fn(ir, vis)
-        if self._static is None or self._key != (tuple(ir.shape), self._model_key()):
-            self._capture(ir, vis)
-        s_ir, s_vis, s_out = self._static
+        if self._overlapped(ir):
+            lane = self._issue(ir, vis)
+            torch.cuda.current_stream(ir.device).wait_stream(lane.stream)
+            return lane.static[2]
+        lane = self._ready_lane(self._lanes[0], ir, vis)
+        s_ir, s_vis, s_out = lane.static
         s_ir.copy_(ir)
         s_vis.copy_(vis)
-        self._graph.replay()
+        lane.graph.replay()
         return s_out
 
     # -- collective ------------------------------------------------------------------------------
     def gather_async(self, local_out: torch.Tensor) -> GatherHandle:
         if self.world_size == 1 and not self.force_collective:
             return GatherHandle(local_out)
-        self._slot ^= 1
+        self._slot = (self._slot + 1) % len(self._stage)
         k = self._slot
         shape = (self.world_size * local_out.shape[0],) + tuple(local_out.shape[1:])
         if self._gathered[k] is None or self._gathered[k].shape != shape or self._gathered[k].device != local_out.device:
             self._gathered[k] = torch.empty(shape, dtype=local_out.dtype, device=local_out.device)
             self._stage[k] = torch.empty(tuple(local_out.shape), dtype=local_out.dtype, device=local_out.device)
+        if self._slot_work[k] is not None:   # the slot's previous collective reads the staging buffer: order this stream behind it
+            self._slot_work[k].wait()
         self._stage[k].copy_(local_out)   # the collective reads a buffer nothing rewrites while it is in flight
         if local_out.is_cuda:
             work = dist.all_gather_into_tensor(self._gathered[k], self._stage[k], group=self.group, async_op=True)
         else:   # gloo
             work = dist.all_gather(list(self._gathered[k].chunk(self.world_size, dim=0)), self._stage[k], group=self.group, async_op=True)
+        self._slot_work[k] = work
         return GatherHandle(self._gathered[k], work)
 
     def gather(self, local_out: torch.Tensor) -> torch.Tensor:
         return self.gather_async(local_out).wait()
 
     def step_async(self, ir_shard: torch.Tensor, vis_shard: torch.Tensor) -> GatherHandle:
-        return self.gather_async(self.local_forward(ir_shard, vis_shard))
+        if not self._overlapped(ir_shard):
+            return self.gather_async(self.local_forward(ir_shard, vis_shard))
+        lane = self._issue(ir_shard, vis_shard)
+        with torch.cuda.stream(lane.stream):      # staging copy and the collective's start are ordered behind the lane's graph
+            handle = self.gather_async(lane.static[2])
+            if handle._work is None:
+                handle._event = lane.stream.record_event()
+        return handle
 
     def step(self, ir_shard: torch.Tensor, vis_shard: torch.Tensor) -> torch.Tensor:
         return self.step_async(ir_shard, vis_shard).wait()

@@ -515,6 +515,51 @@ def test_pipelined_gather_on_a_one_rank_rccl_group():
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("collective", [False, True], ids=["local", "one_rank_rccl"])
+def test_steps_in_flight_keep_their_own_results(collective):
+    """ShardedFusion(in_flight=2), the way bench.py drives it: step i+1 is enqueued on the other lane (own hipGraph, static buffers,
+    workspace, stream) before step i is waited for.  Six different batches: every handle must deliver its own step's output, equal
+    bit for bit to the eager forward; a weight change re-captures both lanes."""
+    import torch.distributed as dist
+    created = False
+    if collective and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29700 + os.getpid() % 200))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+        created = True
+    try:
+        cfg = CONFIGS["win8_4stage"]
+        m = MyModel(**cfg.model_kwargs(_elu())).eval()
+        load_recipe_into(m, seed=0, flavor="default")
+        m.to(DEV)
+        runner = ShardedFusion(m, world_size=1, rank=0, use_graph=True, in_flight=2, force_collective=collective)
+        batches = [tuple(torch.from_numpy(a).to(DEV) for a in synthetic_pair(2, 128, 128, 10 + 2 * i, 11 + 2 * i)) for i in range(6)]
+        want = [m(ir, vis).clone() for ir, vis in batches]
+        got, pending = [], []
+        for ir, vis in batches:
+            pending.append(runner.step_async(ir, vis))
+            if len(pending) == 2:
+                got.append(pending.pop(0).wait().clone())
+        got.append(pending.pop(0).wait().clone())
+        assert runner.captures == 2 and runner.graph_active
+        assert runner._lanes[0].stream.cuda_stream != runner._lanes[1].stream.cuda_stream
+        assert runner._lanes[0].ws_ref.data_ptr() != runner._lanes[1].ws_ref.data_ptr()
+        for i, (g, w) in enumerate(zip(got, want)):
+            assert torch.equal(g, w), i
+        assert not torch.equal(got[0], got[1])
+        other = MyModel(**cfg.model_kwargs(_elu())).eval()
+        load_recipe_into(other, seed=9, flavor="stress")
+        m.load_state_dict(other.state_dict(), strict=True)
+        h1, h2 = runner.step_async(*batches[0]), runner.step_async(*batches[1])
+        o1, o2 = h1.wait().clone(), h2.wait().clone()
+        assert runner.captures == 4
+        assert torch.equal(o1, m(*batches[0])) and torch.equal(o2, m(*batches[1])) and not torch.equal(o1, got[0])
+        assert torch.equal(runner.step(*batches[2]), m(*batches[2]))      # step() waits at once: serial use of the same lanes
+    finally:
+        if created:
+            dist.destroy_process_group()
+
+
 def test_load_state_dict_roundtrip_refreshes_arena():
     cfg = CONFIGS["tiny"]
     a = MyModel(**cfg.model_kwargs(_elu())).eval()

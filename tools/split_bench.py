@@ -68,7 +68,37 @@ def main():
         runs.append({"chains": k, "pairs_per_chain": per, "ms_per_forward": round(ms, 4), "pairs_per_s": round(b / ms * 1e3, 1),
                      "max_abs_diff_vs_one_chain": err})
         del runners, streams, outs
-    print(json.dumps({"what": f"B={b} {n}x{n} {args.config}: k sub-batch graphs replayed on k streams per forward", "runs": runs}))
+    # steps in flight: k runners of the FULL batch on k streams, consecutive steps alternate between them and only the end is joined
+    piped = []
+    for k in (1, 2, 3):
+        runners = [ShardedFusion(model, use_graph=True) for _ in range(k)]
+        streams = [torch.cuda.Stream(device=dev) for _ in range(k)]
+        for r in runners:
+            r.local_forward(ir, vis)
+        torch.cuda.synchronize()
+        err = max(float((r._static[2] - ref).abs().max()) for r in runners)
+
+        def run(nsteps):
+            for s in streams:
+                s.wait_stream(main_s)
+            for i in range(nsteps):
+                with torch.cuda.stream(streams[i % k]):
+                    runners[i % k]._graph.replay()
+            for s in streams:
+                main_s.wait_stream(s)
+
+        run(6)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        run(args.iters)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / args.iters
+        piped.append({"steps_in_flight": k, "ms_per_step": round(ms, 4), "pairs_per_s": round(b / ms * 1e3, 1), "max_abs_diff": err})
+        del runners, streams
+    print(json.dumps({"what": f"B={b} {n}x{n} {args.config}: k sub-batch graphs replayed on k streams per forward", "runs": runs,
+                      "steps_in_flight": piped}))
 
 
 if __name__ == "__main__":
