@@ -45,7 +45,9 @@ def parse():
     ap.add_argument("--config", default="win8")
     ap.add_argument("--precision", default="fast", choices=["fast", "fp32"])
     ap.add_argument("--no-graph", action="store_true", help="launch eagerly instead of replaying a hipGraph")
-    ap.add_argument("--in-flight", type=int, default=2, help="steps kept in flight per GPU (hipGraph lanes on separate streams; 1 = one chain)")
+    ap.add_argument("--in-flight", type=int, default=3,
+                    help="steps kept in flight per GPU (hipGraph lanes on streams measured to sit on distinct hardware queues; the runner "
+                         "keeps fewer if the device has fewer free queues; 1 = one chain)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs per CPU-baseline forward")
     ap.add_argument("--cpu-iters", type=int, default=3)

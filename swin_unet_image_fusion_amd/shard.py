@@ -43,6 +43,48 @@ class GatherHandle:
         return self._tensor
 
 
+def _spin_ms(streams, cycles: int) -> float:
+    """Host-timed duration of one spin kernel (torch.cuda._sleep: a single thread) on each of `streams`, started together."""
+    import time
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for s in streams:
+        with torch.cuda.stream(s):
+            torch.cuda._sleep(cycles)
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t0) * 1e3
+
+
+def concurrent_streams(device, n: int, avoid=(), candidates: int = 12):
+    """n torch streams whose kernels really run side by side, none sharing a hardware queue with a stream in `avoid`.
+
+    HIP maps streams onto a few hardware queues (4 by default) in first-use order, not one each (measured on this image: the null
+    stream and the 7th created stream share queue 1, the 3rd and 4th share queue 4, ...), and two streams on one hardware queue
+    execute their kernels in order: lanes that land on one queue overlap nothing.  Which streams collide depends on what the process
+    created before (RCCL's streams, other runners), so it is measured: two one-thread spin kernels on two streams take one spin time
+    on different queues and two on the same queue.  Returns fewer than n streams if the device has no more distinct queues."""
+    cycles = 200_000
+    probe = torch.cuda.Stream(device=device)
+    _spin_ms([probe], cycles)                                   # warm-up (first use creates the queue)
+    one = min(_spin_ms([probe], cycles) for _ in range(3))
+    if one < 0.2:                                               # aim at ~0.4 ms per spin: well above launch and sync noise
+        cycles = int(cycles * 0.4 / max(one, 1e-3))
+        one = min(_spin_ms([probe], cycles) for _ in range(3))
+
+    def overlap(a, b) -> bool:
+        _spin_ms([a, b], cycles)
+        return min(_spin_ms([a, b], cycles) for _ in range(2)) < 1.5 * one
+
+    chosen = []
+    pool = [probe] + [torch.cuda.Stream(device=device) for _ in range(candidates - 1)]
+    for c in pool:
+        if len(chosen) == n:
+            break
+        if all(overlap(c, o) for o in list(avoid) + chosen):
+            chosen.append(c)
+    return chosen
+
+
 class _Lane:
     """One captured forward: the hipGraph, the runner-owned static input / output buffers it was captured on, the key it was captured
     for, its capture stream (also the stream it replays on when steps overlap) and the library workspace it points into."""
@@ -92,6 +134,7 @@ class ShardedFusion:
         self.in_flight = in_flight
         self.graph_active = False
         self._lanes = [_Lane() for _ in range(in_flight)]
+        self._lane_streams_ready = False
         self._turn = 0
         nslots = in_flight + 1   # step i+1 .. i+in_flight may run while step i's result is still being gathered / read
         self._gathered = [None] * nslots
@@ -140,7 +183,23 @@ class ShardedFusion:
         lane.key = (tuple(ir.shape), self._model_key())   # after the capture: the arena / packed images exist now
         self.captures += 1
 
+    def _pick_lane_streams(self, device):
+        """Overlapped lanes need streams on distinct hardware queues (concurrent_streams); with fewer distinct queues than lanes the
+        runner keeps as many lanes as it found queues for."""
+        got = concurrent_streams(device, self.in_flight, avoid=[torch.cuda.current_stream(device)])
+        if not got:
+            got = [torch.cuda.Stream(device=device)]
+        if len(got) < self.in_flight:
+            self._lanes, self.in_flight = self._lanes[:len(got)], len(got)
+            self._turn = 0
+        for lane, s in zip(self._lanes, got):
+            lane.stream = s
+        self._lane_streams_ready = True
+
     def _ready_lane(self, lane: _Lane, ir, vis) -> _Lane:
+        if self.in_flight > 1 and not self._lane_streams_ready:
+            self._pick_lane_streams(ir.device)
+            lane = self._lanes[self._turn]
         if lane.static is None or lane.key != (tuple(ir.shape), self._model_key()):
             self._capture(lane, ir, vis)
         return lane

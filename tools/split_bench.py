@@ -22,6 +22,8 @@ def main():
     ap.add_argument("--size", type=int, default=256)
     ap.add_argument("--iters", type=int, default=50)
     ap.add_argument("--config", default="win8")
+    ap.add_argument("--chains", type=int, nargs="*", default=[1, 2, 4, 8])
+    ap.add_argument("--in-flight", type=int, nargs="*", default=[1, 2, 3])
     args = ap.parse_args()
     entry.build()
     from swin_unet_image_fusion_amd import CONFIGS, MyModel, load_recipe_into, synthetic_pair
@@ -37,7 +39,7 @@ def main():
     ref = model(ir, vis).clone()
     runs = []
     main_s = torch.cuda.current_stream(dev)
-    for k in (1, 2, 4, 8):
+    for k in args.chains:
         if b % k:
             continue
         per = b // k
@@ -70,7 +72,7 @@ def main():
         del runners, streams, outs
     # steps in flight: k runners of the FULL batch on k streams, consecutive steps alternate between them and only the end is joined
     piped = []
-    for k in (1, 2, 3):
+    for k in args.in_flight:
         runners = [ShardedFusion(model, use_graph=True) for _ in range(k)]
         streams = [torch.cuda.Stream(device=dev) for _ in range(k)]
         for r in runners:
