@@ -48,6 +48,8 @@ def parse():
     ap.add_argument("--in-flight", type=int, default=3,
                     help="steps kept in flight per GPU (hipGraph lanes on streams measured to sit on distinct hardware queues; the runner "
                          "keeps fewer if the device has fewer free queues; 1 = one chain)")
+    ap.add_argument("--force-collective", action="store_true",
+                    help="one GPU only: issue the per-step all-gather on a one-rank RCCL group (rehearses the N>1 stream / queue pattern)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-pairs", type=int, default=4, help="pairs per CPU-baseline forward")
     ap.add_argument("--cpu-iters", type=int, default=3)
@@ -301,6 +303,10 @@ def main():
         torch.cuda.set_device(local)
         dev = torch.device("cuda", local)
         sync = torch.cuda.synchronize
+    if world == 1 and args.force_collective and not dry:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
@@ -326,7 +332,7 @@ def main():
         model.to(dev)
         model.precision = args.precision
         runner = ShardedFusion(model, world_size=world, rank=rank, use_graph=not args.no_graph,
-                               in_flight=1 if args.no_graph else args.in_flight)
+                               in_flight=1 if args.no_graph else args.in_flight, force_collective=args.force_collective and world == 1)
 
     # synthetic IR / visible pairs, distinct per rank, resident in HBM before the timed region
     hh, ww_ = args.height or args.size, args.width or args.size
@@ -393,7 +399,8 @@ def main():
                        "steps_in_flight": runner.in_flight if runner.graph_active else 1,
                        "one_step_at_a_time": None if serial_ms is None else
                        {"ms_per_step": round(serial_ms, 4), "pairs_per_s": round(args.batch * world / serial_ms * 1e3, 1)},
-                       "collective": "rccl all_gather_into_tensor of the fused output per step, overlapped with the next step's forward" if world > 1 else "none",
+                       "collective": "rccl all_gather_into_tensor of the fused output per step, overlapped with the next steps' forwards" if world > 1 else
+                                     ("one-rank rccl all_gather_into_tensor per step (rehearsal)" if args.force_collective else "none"),
                        "weights": "random-init (numpy PCG64 recipe, seed 0)"},
         }
         if dry:
@@ -411,6 +418,7 @@ def main():
         print(json.dumps(line), flush=True)
     if world > 1:
         dist.barrier()
+    if dist.is_initialized():
         dist.destroy_process_group()
 
 

@@ -85,6 +85,29 @@ def concurrent_streams(device, n: int, avoid=(), candidates: int = 12):
     return chosen
 
 
+class _DeferredGather(GatherHandle):
+    """Handle of an overlapped step whose all-gather has not been started yet (ShardedFusion.step_async): the runner starts it
+    in_flight - 1 steps later, or wait() does — always oldest first, so every rank issues its collectives in the same order.
+    Every handle must be waited for on every rank."""
+
+    def __init__(self, runner, slot: int, lane_stream):
+        super().__init__(runner._gathered[slot])
+        self._runner, self._slot, self._lane_stream, self._issued = runner, slot, lane_stream, False
+
+    def _start(self) -> None:
+        if self._issued:
+            return
+        r, k = self._runner, self._slot
+        with torch.cuda.stream(self._lane_stream):     # RCCL's stream waits for the lane's staging copy, not for the caller's stream
+            work = dist.all_gather_into_tensor(r._gathered[k], r._stage[k], group=r.group, async_op=True)
+        r._slot_work[k] = self._work = work
+        self._issued = True
+
+    def wait(self) -> torch.Tensor:
+        self._runner._start_through(self)
+        return super().wait()
+
+
 class _Lane:
     """One captured forward: the hipGraph, the runner-owned static input / output buffers it was captured on, the key it was captured
     for, its capture stream (also the stream it replays on when steps overlap) and the library workspace it points into."""
@@ -141,6 +164,7 @@ class ShardedFusion:
         self._stage = [None] * nslots
         self._slot_work = [None] * nslots
         self._slot = 0
+        self._unissued = []      # deferred collectives of overlapped steps, oldest first
         self.captures = 0
 
     # (the first lane under its old names: tests and tools look at them)
@@ -237,17 +261,21 @@ class ShardedFusion:
         return s_out
 
     # -- collective ------------------------------------------------------------------------------
+    def _next_slot(self, like: torch.Tensor) -> int:
+        self._slot = (self._slot + 1) % len(self._stage)
+        k = self._slot
+        shape = (self.world_size * like.shape[0],) + tuple(like.shape[1:])
+        if self._gathered[k] is None or self._gathered[k].shape != shape or self._gathered[k].device != like.device:
+            self._gathered[k] = torch.empty(shape, dtype=like.dtype, device=like.device)
+            self._stage[k] = torch.empty(tuple(like.shape), dtype=like.dtype, device=like.device)
+        if self._slot_work[k] is not None:   # the slot's previous collective reads the staging buffer: order this stream behind it
+            self._slot_work[k].wait()
+        return k
+
     def gather_async(self, local_out: torch.Tensor) -> GatherHandle:
         if self.world_size == 1 and not self.force_collective:
             return GatherHandle(local_out)
-        self._slot = (self._slot + 1) % len(self._stage)
-        k = self._slot
-        shape = (self.world_size * local_out.shape[0],) + tuple(local_out.shape[1:])
-        if self._gathered[k] is None or self._gathered[k].shape != shape or self._gathered[k].device != local_out.device:
-            self._gathered[k] = torch.empty(shape, dtype=local_out.dtype, device=local_out.device)
-            self._stage[k] = torch.empty(tuple(local_out.shape), dtype=local_out.dtype, device=local_out.device)
-        if self._slot_work[k] is not None:   # the slot's previous collective reads the staging buffer: order this stream behind it
-            self._slot_work[k].wait()
+        k = self._next_slot(local_out)
         self._stage[k].copy_(local_out)   # the collective reads a buffer nothing rewrites while it is in flight
         if local_out.is_cuda:
             work = dist.all_gather_into_tensor(self._gathered[k], self._stage[k], group=self.group, async_op=True)
@@ -259,14 +287,29 @@ class ShardedFusion:
     def gather(self, local_out: torch.Tensor) -> torch.Tensor:
         return self.gather_async(local_out).wait()
 
+    def _start_through(self, handle) -> None:
+        """Start the deferred collectives up to and including `handle`, oldest first (every rank starts them in the same order)."""
+        while self._unissued and not handle._issued:
+            self._unissued.pop(0)._start()
+
     def step_async(self, ir_shard: torch.Tensor, vis_shard: torch.Tensor) -> GatherHandle:
         if not self._overlapped(ir_shard):
             return self.gather_async(self.local_forward(ir_shard, vis_shard))
         lane = self._issue(ir_shard, vis_shard)
-        with torch.cuda.stream(lane.stream):      # staging copy and the collective's start are ordered behind the lane's graph
-            handle = self.gather_async(lane.static[2])
-            if handle._work is None:
-                handle._event = lane.stream.record_event()
+        if self.world_size == 1 and not self.force_collective:
+            return GatherHandle(lane.static[2], event=lane.stream.record_event())
+        with torch.cuda.stream(lane.stream):      # the staging copy is ordered behind the lane's graph
+            k = self._next_slot(lane.static[2])
+            self._stage[k].copy_(lane.static[2])
+        # The collective itself starts in_flight - 1 steps LATER.  RCCL's stream shares one of the 4 hardware queues with a lane (or
+        # the caller); started now, its wait for THIS step would sit in that queue in front of the other lane's next graph and hold
+        # it until this step is done - the lanes would run one after the other (measured: 3 lanes + immediate gather = 6 670 pairs/s,
+        # the one-chain rate).  Started after the next in_flight - 1 steps are enqueued, everything queued in front of it is work that
+        # runs before this step completes anyway.
+        handle = _DeferredGather(self, k, lane.stream)
+        self._unissued.append(handle)
+        while len(self._unissued) > self.in_flight - 1:
+            self._unissued.pop(0)._start()
         return handle
 
     def step(self, ir_shard: torch.Tensor, vis_shard: torch.Tensor) -> torch.Tensor:

@@ -515,8 +515,9 @@ def test_pipelined_gather_on_a_one_rank_rccl_group():
             dist.destroy_process_group()
 
 
+@pytest.mark.parametrize("lanes", [2, 3])
 @pytest.mark.parametrize("collective", [False, True], ids=["local", "one_rank_rccl"])
-def test_steps_in_flight_keep_their_own_results(collective):
+def test_steps_in_flight_keep_their_own_results(collective, lanes):
     """ShardedFusion(in_flight=2), the way bench.py drives it: step i+1 is enqueued on the other lane (own hipGraph, static buffers,
     workspace, stream) before step i is waited for.  Six different batches: every handle must deliver its own step's output, equal
     bit for bit to the eager forward; a weight change re-captures both lanes."""
@@ -532,18 +533,21 @@ def test_steps_in_flight_keep_their_own_results(collective):
         m = MyModel(**cfg.model_kwargs(_elu())).eval()
         load_recipe_into(m, seed=0, flavor="default")
         m.to(DEV)
-        runner = ShardedFusion(m, world_size=1, rank=0, use_graph=True, in_flight=2, force_collective=collective)
-        batches = [tuple(torch.from_numpy(a).to(DEV) for a in synthetic_pair(2, 128, 128, 10 + 2 * i, 11 + 2 * i)) for i in range(6)]
+        runner = ShardedFusion(m, world_size=1, rank=0, use_graph=True, in_flight=lanes, force_collective=collective)
+        batches = [tuple(torch.from_numpy(a).to(DEV) for a in synthetic_pair(2, 128, 128, 10 + 2 * i, 11 + 2 * i)) for i in range(7)]
         want = [m(ir, vis).clone() for ir, vis in batches]
         got, pending = [], []
         for ir, vis in batches:
             pending.append(runner.step_async(ir, vis))
-            if len(pending) == 2:
+            if len(pending) == lanes:
                 got.append(pending.pop(0).wait().clone())
-        got.append(pending.pop(0).wait().clone())
-        assert runner.captures == 2 and runner.graph_active
-        assert runner._lanes[0].stream.cuda_stream != runner._lanes[1].stream.cuda_stream
-        assert runner._lanes[0].ws_ref.data_ptr() != runner._lanes[1].ws_ref.data_ptr()
+        while pending:
+            got.append(pending.pop(0).wait().clone())
+        lanes = runner.in_flight          # (the runner keeps as many lanes as it found distinct hardware queues for: >= 2 on this device)
+        assert lanes >= 2 and runner.captures == lanes and runner.graph_active
+        assert len({ln.stream.cuda_stream for ln in runner._lanes}) == lanes
+        assert len({ln.ws_ref.data_ptr() for ln in runner._lanes}) == lanes
+        assert not runner._unissued
         for i, (g, w) in enumerate(zip(got, want)):
             assert torch.equal(g, w), i
         assert not torch.equal(got[0], got[1])
@@ -552,7 +556,7 @@ def test_steps_in_flight_keep_their_own_results(collective):
         m.load_state_dict(other.state_dict(), strict=True)
         h1, h2 = runner.step_async(*batches[0]), runner.step_async(*batches[1])
         o1, o2 = h1.wait().clone(), h2.wait().clone()
-        assert runner.captures == 4
+        assert runner.captures == lanes + 2
         assert torch.equal(o1, m(*batches[0])) and torch.equal(o2, m(*batches[1])) and not torch.equal(o1, got[0])
         assert torch.equal(runner.step(*batches[2]), m(*batches[2]))      # step() waits at once: serial use of the same lanes
     finally:
