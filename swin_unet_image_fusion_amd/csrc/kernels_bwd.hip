@@ -26,7 +26,8 @@
 namespace swf {
 namespace {
 
-constexpr int kChunk = 2048;   // tokens per partial sum of bwd_dw / bwd_colsum
+constexpr int kChunk = 256;    // tokens per partial sum of bwd_dw / bwd_colsum (level 0 at B=16: 1 024 chunks fill the chip)
+constexpr int kGroup = 32;     // partial rows summed per thread and tree level (reduce_rows)
 
 // out[M][K] (+)= dY[M][N] . W[N][K]
 __global__ __launch_bounds__(256) void bwd_dx_kernel(const float* __restrict__ dY, const float* __restrict__ W, float* __restrict__ out,
@@ -109,23 +110,33 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const float* __restrict__ d
         }
 }
 
-// partial[chunk][N] = column sums of dY over the chunk's tokens
-__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float* __restrict__ dY, float* __restrict__ partial, int M, int N) {
-    const int chunk = blockIdx.y, n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+// partial[chunk][N] = column sums of dY over the chunk's tokens.  The block covers NP = min(256, pow2 >= N) columns with 256 / NP row
+// lanes: lane j sums rows mlo + j, mlo + j + RL, ... and the lanes are added in index order (fixed order: bit-reproducible).
+__global__ __launch_bounds__(256) void bwd_colsum_kernel(const float* __restrict__ dY, float* __restrict__ partial, int M, int N, int NP) {
+    __shared__ float red[256];
+    const int chunk = blockIdx.y, RL = 256 / NP;
+    const int col = threadIdx.x % NP, lane = threadIdx.x / NP, n = blockIdx.x * NP + col;
     const int mlo = chunk * kChunk, mhi = min(M, mlo + kChunk);
     float s = 0.f;
-    for (int m = mlo; m < mhi; ++m) s += dY[(int64_t)m * N + n];
-    partial[(int64_t)chunk * N + n] = s;
+    if (n < N)
+        for (int m = mlo + lane; m < mhi; m += RL) s += dY[(int64_t)m * N + n];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    if (lane == 0 && n < N) {
+        float t = red[col];
+        for (int j = 1; j < RL; ++j) t += red[j * NP + col];
+        partial[(int64_t)chunk * N + n] = t;
+    }
 }
 
-// out[i] = sum_r partial[r][i], r in index order
+// out[g][i] = sum of partial[r][i] over the rows r of group g (kGroup consecutive rows; blockIdx.y = g), r in index order
 __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restrict__ partial, float* __restrict__ out, int64_t count, int rows) {
     const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= count) return;
+    const int r0 = blockIdx.y * kGroup, r1 = min(rows, r0 + kGroup);
     float s = 0.f;
-    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * count + i];
-    out[i] = s;
+    for (int r = r0; r < r1; ++r) s += partial[(int64_t)r * count + i];
+    out[(int64_t)blockIdx.y * count + i] = s;
 }
 
 __global__ __launch_bounds__(256) void elu_bwd_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t count) {
@@ -401,26 +412,49 @@ int dx(const float* dY, const float* W, float* out, int64_t M, int N, int K, int
     return check_launch("bwd_dx");
 }
 int chunks_of(int64_t M) { return (int)cdiv64(M, kChunk); }
-// dW [N][K] (and db [N] when asked) of a linear layer y = x W^T + b from dY [M][N] and X [M][K]; scratch: chunks * N * (K + 1) floats
+// Sum of `rows` partial rows of `count` floats in a fixed tree: kGroup consecutive rows per thread and level, levels in sequence
+// (sequential sums of 131 072 per-window rows of the bias-table gradient took 13 ms a call).  The intermediate levels live BEHIND the
+// partial rows: the buffer holds tree_rows(rows) rows.
+int64_t tree_rows(int64_t rows) {
+    int64_t t = rows;
+    while (rows > kGroup) { rows = cdiv64(rows, kGroup); t += rows; }
+    return t;
+}
+int reduce_rows(float* partial, float* out, int64_t count, int64_t rows, hipStream_t st) {
+    float* src = partial;
+    while (rows > kGroup) {
+        const int64_t g = cdiv64(rows, kGroup);
+        float* dst = src + rows * count;
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv64(count, 256), (unsigned)g), dim3(256), 0, st, src, dst, count, (int)rows);
+        SWF_TRY(check_launch("reduce_rows level"));
+        src = dst; rows = g;
+    }
+    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv64(count, 256), 1), dim3(256), 0, st, src, out, count, (int)rows);
+    return check_launch("reduce_rows");
+}
+int colsum_np(int N) { int np = 1; while (np < N && np < 256) np *= 2; return np; }
+int colsum(const float* dY, float* partial, int64_t M, int N, hipStream_t st) {
+    const int np = colsum_np(N);
+    hipLaunchKernelGGL(bwd_colsum_kernel, dim3(cdiv(N, np), chunks_of(M)), dim3(256), 0, st, dY, partial, (int)M, N, np);
+    return check_launch("bwd_colsum");
+}
+// dW [N][K] (and db [N] when asked) of a linear layer y = x W^T + b from dY [M][N] and X [M][K]; scratch: tree_rows(chunks) * N * (K + 1) floats
 int dw(const float* dY, const float* X, float* dW, float* db, int64_t M, int N, int K, float* scratch, hipStream_t st) {
     const int ch = chunks_of(M);
     if (dW) {
         hipLaunchKernelGGL(bwd_dw_kernel, dim3(cdiv(K, 64), cdiv(N, 64), ch), dim3(256), 0, st, dY, X, scratch, (int)M, N, K);
         SWF_TRY(check_launch("bwd_dw"));
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv64((int64_t)N * K, 256)), dim3(256), 0, st, scratch, dW, (int64_t)N * K, ch);
-        SWF_TRY(check_launch("bwd_dw reduce"));
+        SWF_TRY(reduce_rows(scratch, dW, (int64_t)N * K, ch, st));
     }
     if (db) {
-        float* ps = scratch + (int64_t)ch * N * K;
-        hipLaunchKernelGGL(bwd_colsum_kernel, dim3(cdiv(N, 256), ch), dim3(256), 0, st, dY, ps, (int)M, N);
-        SWF_TRY(check_launch("bwd_colsum"));
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(N, 256)), dim3(256), 0, st, ps, db, (int64_t)N, ch);
-        SWF_TRY(check_launch("bwd_colsum reduce"));
+        float* ps = scratch + tree_rows(ch) * N * K;
+        SWF_TRY(colsum(dY, ps, M, N, st));
+        SWF_TRY(reduce_rows(ps, db, (int64_t)N, ch, st));
     }
     return SWF_OK;
 }
 int ln_blocks(int64_t M) { return (int)cdiv64(M, 4 * kLnRows); }
-// dx = dres + LayerNorm backward of dy; d gamma / d beta (either may be NULL); scratch: ln_blocks * 4 * 2 * C + 2 * C floats
+// dx = dres + LayerNorm backward of dy; d gamma / d beta (either may be NULL); scratch: tree_rows(ln_blocks * 4) * 2 * C + 2 * C floats
 int ln_bwd(const float* x, const float* gamma, const float* dy, const float* dres, float* dxo, float* dgamma, float* dbeta, int64_t M, int C,
            float* scratch, hipStream_t st) {
     if (C > 64 * kLnMaxCh) return fail(SWF_ERR_UNSUPPORTED, "LayerNorm backward: C = %d > %d", C, 64 * kLnMaxCh);
@@ -428,13 +462,17 @@ int ln_bwd(const float* x, const float* gamma, const float* dy, const float* dre
     hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(256), 0, st, x, gamma, dy, dres, dxo, scratch, M, C);
     SWF_TRY(check_launch("ln_bwd"));
     if (dgamma || dbeta) {
-        float* red = scratch + (int64_t)nb * 4 * 2 * C;
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(2 * C, 256)), dim3(256), 0, st, scratch, red, (int64_t)2 * C, nb * 4);
-        SWF_TRY(check_launch("ln_bwd reduce"));
+        float* red = scratch + tree_rows((int64_t)nb * 4) * 2 * C;
+        SWF_TRY(reduce_rows(scratch, red, (int64_t)2 * C, (int64_t)nb * 4, st));
         if (dgamma && hipMemcpyAsync(dgamma, red, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SWF_ERR_HIP, "ln_bwd: copy failed");
         if (dbeta && hipMemcpyAsync(dbeta, red + C, (size_t)C * 4, hipMemcpyDeviceToDevice, st) != hipSuccess) return fail(SWF_ERR_HIP, "ln_bwd: copy failed");
     }
     return SWF_OK;
+}
+
+// scratch shared by dw() and ln_bwd() of a layer with M tokens, widest matrix dimension mx and C normalised channels
+int64_t bwd_scratch_floats(int64_t M, int64_t mx, int64_t C) {
+    return std::max(tree_rows(chunks_of(M)) * mx * (mx + 1), tree_rows((int64_t)ln_blocks(M) * 4) * 2 * C + 2 * C) + 64;
 }
 
 }  // namespace
@@ -447,8 +485,8 @@ size_t basic_block_bwd_ws(const swf_block_desc& d, int nstream, int B, int H, in
     for (int s = 0; s < nstream; ++s)
         t += carve_bytes({N * C, N * HD, N * HD, N * HD, N * HD, N * C, N * C, N * hid,      // xn, q, k, v, o, x1, xn2, h
                           N * hid, N * C, N * C, N * HD, N * HD, N * HD, N * HD, N * C,      // dh, dxn2, gx1, do, dq, dk, dv, dxn
-                          nwin * d.attn.heads * tsz});
-    t += carve_bytes({(int64_t)chunks_of(N) * mx * (mx + 1) + (int64_t)ln_blocks(N) * 8 * C + 2 * C + 64});
+                          tree_rows(nwin * d.attn.heads) * tsz});
+    t += carve_bytes({bwd_scratch_floats(N, mx, C)});
     return t;
 }
 
@@ -469,10 +507,10 @@ int basic_block_bwd(const swf_block_desc& d, const swf_block_stream_params* px, 
         b[s].x1 = ws.floats(N * C); b[s].xn2 = ws.floats(N * C); b[s].h = ws.floats(N * hid);
         b[s].dh = ws.floats(N * hid); b[s].dxn2 = ws.floats(N * C); b[s].gx1 = ws.floats(N * C); b[s].dO = ws.floats(N * HD);
         b[s].dq = ws.floats(N * HD); b[s].dk = ws.floats(N * HD); b[s].dv = ws.floats(N * HD); b[s].dxn = ws.floats(N * C);
-        b[s].dtab = ws.floats(nwin * d.attn.heads * tsz);
+        b[s].dtab = ws.floats(tree_rows(nwin * d.attn.heads) * tsz);
     }
     const int64_t mx = std::max(std::max(C, HD), hid);
-    float* scratch = ws.floats((int64_t)chunks_of(N) * mx * (mx + 1) + (int64_t)ln_blocks(N) * 8 * C + 2 * C + 64);
+    float* scratch = ws.floats(bwd_scratch_floats(N, mx, C));
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "basic_block_bwd workspace too small (need %zu B)", ws.used);
     const swf_block_stream_params* pp[2] = {px, py};
     const swf_block_stream_grads* gp[2] = {gx, gy};
@@ -527,9 +565,7 @@ int basic_block_bwd(const swf_block_desc& d, const swf_block_stream_params* px, 
         SWF_TRY(launch_attn_bwd(ab, nstream, HD, B, H, W, wh, ww, d.attn.heads, d.attn.head_dim, d.attn.shift, st));
         for (int s = 0; s < nstream; ++s)
             if (G(s).attn.bias_table) {
-                hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(tsz, 256)), dim3(256), 0, st, b[s].dtab, G(s).attn.bias_table, (int64_t)tsz,
-                                   (int)(nwin * d.attn.heads));
-                SWF_TRY(check_launch("dtable reduce"));
+                SWF_TRY(reduce_rows(b[s].dtab, G(s).attn.bias_table, (int64_t)tsz, nwin * d.attn.heads, st));
             }
     }
     // ---- Q / K / V projections, reverse: stream s's K and V read the normalised tokens of stream kvs (a002:67-82) ----
@@ -554,7 +590,7 @@ size_t patch_bwd_ws(int B, int H, int W, int Cin, int Cout, int mh, int mw, int 
     const int64_t K = encoder ? (int64_t)Cin * mh * mw : Cin, Nn = encoder ? Cout : (int64_t)Cout * mh * mw;
     const int64_t mx = std::max(K, Nn);
     return carve_bytes({n * K, n * Nn, n * Nn, n * Nn, n * Nn, n * K}) +
-           carve_bytes({(int64_t)chunks_of(n) * mx * (mx + 1) + (int64_t)ln_blocks(n) * 8 * Nn + 2 * Nn + 64});
+           carve_bytes({bwd_scratch_floats(n, mx, Nn)});
 }
 
 int patch_bwd(const swf_patch_params& p, const float* in, const float* gout, float* gin, const swf_patch_grads* gp, int B, int H, int W, int Cin,
@@ -573,7 +609,7 @@ int patch_bwd(const swf_patch_params& p, const float* in, const float* gout, flo
     float* dV = ws.floats(n * Nn);
     float* dZ = ws.floats(n * K);
     const int64_t mx = std::max(K, Nn);
-    float* scratch = ws.floats((int64_t)chunks_of(n) * mx * (mx + 1) + (int64_t)ln_blocks(n) * 8 * Nn + 2 * Nn + 64);
+    float* scratch = ws.floats(bwd_scratch_floats(n, mx, Nn));
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "patch backward workspace too small (need %zu B)", ws.used);
     const swf_patch_grads none{};
     const swf_patch_grads& g = gp ? *gp : none;
@@ -781,7 +817,7 @@ __global__ __launch_bounds__(256) void head_split_kernel(const float* __restrict
 
 size_t head_bwd_ws(int B, int H, int W, int ks) {
     const int64_t n = (int64_t)B * H * W, nc = 4 * ks * ks + 6;
-    return carve_bytes({2 * n, 2 * n, 2 * n, n * nc, (int64_t)chunks_of(n) * nc + nc + 64});
+    return carve_bytes({2 * n, 2 * n, 2 * n, n * nc, tree_rows(chunks_of(n)) * nc + nc + 64});
 }
 
 int head_batch_stats(const swf_head_params& p, const float* x, const float* y, float* mean, float* var, float* running_mean, float* running_var,
@@ -791,20 +827,18 @@ int head_batch_stats(const swf_head_params& p, const float* x, const float* y, f
     Carver ws(workspace, workspace_bytes);
     float* t1 = ws.floats(2 * n);
     float* rows = ws.floats(2 * n);
-    float* part = ws.floats((int64_t)chunks_of(n) * 2 + 64);
+    float* part = ws.floats(tree_rows(chunks_of(n)) * 2 + 64);
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "head statistics workspace too small (need %zu B)", ws.used);
     const unsigned blocks = (unsigned)cdiv64(n, 256);
     const int ch = chunks_of(n);
-    float* sums = part + (int64_t)ch * 2;
+    float* sums = part + tree_rows(ch) * 2;
     hipLaunchKernelGGL(head_t1_kernel, dim3(blocks), dim3(256), 0, st, x, y, t1, p, B, H, W, ks);
     SWF_TRY(check_launch("head_t1"));
     for (int pass = 0; pass < 2; ++pass) {
         hipLaunchKernelGGL(head_stat_rows_kernel, dim3(blocks), dim3(256), 0, st, t1, mean, rows, pass, n);
         SWF_TRY(check_launch("head stat rows"));
-        hipLaunchKernelGGL(bwd_colsum_kernel, dim3(1, ch), dim3(256), 0, st, rows, part, (int)n, 2);
-        SWF_TRY(check_launch("head stat colsum"));
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(1), dim3(256), 0, st, part, sums, (int64_t)2, ch);
-        SWF_TRY(check_launch("head stat reduce"));
+        SWF_TRY(colsum(rows, part, n, 2, st));
+        SWF_TRY(reduce_rows(part, sums, 2, ch, st));
         hipLaunchKernelGGL(head_stat_finish_kernel, dim3(1), dim3(64), 0, st, sums, mean, var, running_mean, running_var, momentum, pass, (float)n);
         SWF_TRY(check_launch("head stat finish"));
     }
@@ -821,7 +855,7 @@ int head_bwd(const swf_head_params& p, const float* x, const float* y, const flo
     float* dt2 = ws.floats(2 * n);
     float* din = ws.floats(2 * n);
     float* rows = ws.floats(n * nc1);
-    float* part = ws.floats((int64_t)chunks_of(n) * nc1 + nc1 + 64);
+    float* part = ws.floats(tree_rows(chunks_of(n)) * nc1 + nc1 + 64);
     if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "head backward workspace too small (need %zu B)", ws.used);
     // the BatchNorm constants are four scalars per channel: read them on the host once (a 32-byte synchronous copy per call)
     float hg[2], hb[2], hm[2], hv[2];
@@ -840,13 +874,10 @@ int head_bwd(const swf_head_params& p, const float* x, const float* y, const flo
     hipLaunchKernelGGL(head_conv_adjoint_kernel, dim3(blocks), dim3(256), 0, st, gout, p.conv2_w, dt2, 1, t1, a[0], c[0], a[1], c[1], 1, B, H, W, ks);
     SWF_TRY(check_launch("head adjoint conv2"));
     auto colsums = [&](int nc, float* out_host_layout) -> int {   // column sums of rows [n][nc] -> part tail (device)
-        const int ch = chunks_of(n);
-        hipLaunchKernelGGL(bwd_colsum_kernel, dim3(cdiv(nc, 256), ch), dim3(256), 0, st, rows, part, (int)n, nc);
-        SWF_TRY(check_launch("head colsum"));
-        hipLaunchKernelGGL(reduce_rows_kernel, dim3(cdiv(nc, 256)), dim3(256), 0, st, part, out_host_layout, (int64_t)nc, ch);
-        return check_launch("head colsum reduce");
+        SWF_TRY(colsum(rows, part, n, nc, st));
+        return reduce_rows(part, out_host_layout, nc, chunks_of(n), st);
     };
-    float* sums = part + (int64_t)chunks_of(n) * nc1;
+    float* sums = part + tree_rows(chunks_of(n)) * nc1;
     auto copy = [&](float* dst, const float* src, int count) -> int {
         if (!dst) return SWF_OK;
         return hipMemcpyAsync(dst, src, (size_t)count * 4, hipMemcpyDeviceToDevice, st) == hipSuccess ? SWF_OK : fail(SWF_ERR_HIP, "head backward: copy failed");
