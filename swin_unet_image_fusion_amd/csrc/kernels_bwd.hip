@@ -209,8 +209,10 @@ struct AttnBwdProb {
 };
 struct AttnBwdBatch { AttnBwdProb p[2]; };
 
+// (the recompute form: nothing of size t x t is kept, every pass rebuilds the scores it needs — the fallback for windows whose
+//  probability tile does not fit in LDS, e.g. 16 x 16)
 template <int DMAX>
-__global__ void attn_bwd_kernel(AttnBwdBatch batch, int ld, int B, int H, int W, int wh, int ww, int heads, int d, int shift, float scale) {
+__global__ void attn_bwd_recompute_kernel(AttnBwdBatch batch, int ld, int B, int H, int W, int wh, int ww, int heads, int d, int shift, float scale) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const AttnBwdProb pr = batch.p[blockIdx.z];
     const int t = wh * ww;
@@ -330,20 +332,175 @@ __global__ void attn_bwd_kernel(AttnBwdBatch batch, int ld, int B, int H, int W,
     }
 }
 
+// The resident form: the probability tile P [t][t + 1] of the (window, head) lives in LDS (row stride t + 1: rows by query thread and
+// columns by key thread are both conflict-free), scores and exponentials are computed ONCE:
+//   A1 thread = query i : scores -> LDS, row maximum, exponentials, P_ij, D_i = sum_j P_ij dP_ij
+//   B1 thread = key j   : dV_j = sum_i P_ij dO_i
+//   A2 thread = query i : dS_ij = P_ij (dP_ij - D_i) over P in place, dQ_i = scale sum_j dS_ij K_j
+//   B2 thread = key j   : dK_j = scale sum_i dS_ij Q_i
+//   C  thread = table entry: sum of dS over the (query, key) pairs at that offset
+// Masked scores are ASSIGNED -1e10 (a001:310): their P is exactly 0, so is their dS, and no gradient reaches the table through them.
+template <int DMAX>
+__global__ void attn_bwd_kernel(AttnBwdBatch batch, int ld, int B, int H, int W, int wh, int ww, int heads, int d, int shift, float scale) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const AttnBwdProb pr = batch.p[blockIdx.z];
+    const int t = wh * ww, tp = t + 1;
+    float* Qs = smem;
+    float* Ks = Qs + t * DMAX;
+    float* Vs = Ks + t * DMAX;
+    float* Gs = Vs + t * DMAX;           // dO
+    float* tab = Gs + t * DMAX;
+    const int tw = 2 * ww - 1, tsz = (2 * wh - 1) * tw;
+    float* P = tab + tsz;                // [t][t + 1]
+    float* Drow = P + t * tp;
+    const int nwx = W / ww, nwy = H / wh;
+    const int win = blockIdx.x, head = blockIdx.y;
+    const int b = win / (nwx * nwy), wrem = win % (nwx * nwy);
+    const int wy = wrem / nwx, wx = wrem % nwx;
+    const int sh = shift ? wh / 2 : 0, sw = shift ? ww / 2 : 0;
+    const int tid = threadIdx.x;
+    auto token_of = [&](int j) -> int64_t {
+        const int sy = wy * wh + j / ww, sx = wx * ww + j % ww;
+        const int oy = (sy + sh) % H, ox = (sx + sw) % W;
+        return ((int64_t)b * H + oy) * W + ox;
+    };
+    auto region_of = [&](int j) {
+        const int sy = wy * wh + j / ww, sx = wx * ww + j % ww;
+        return ((sy >= H - wh) + (sy >= H - wh / 2)) * 3 + ((sx >= W - ww) + (sx >= W - ww / 2));
+    };
+    for (int i = tid; i < tsz; i += blockDim.x) tab[i] = pr.bias_table[i];
+    for (int e = tid; e < t * DMAX; e += blockDim.x) {
+        const int j = e / DMAX, c = e % DMAX;
+        float qv = 0.f, kv = 0.f, vv = 0.f, gv = 0.f;
+        if (c < d) {
+            const int64_t o = token_of(j) * ld + head * d + c;
+            qv = pr.Q[o]; kv = pr.K[o]; vv = pr.V[o]; gv = pr.dO[o];
+        }
+        Qs[e] = qv; Ks[e] = kv; Vs[e] = vv; Gs[e] = gv;
+    }
+    __syncthreads();
+    auto dP = [&](int i, int j) -> float {
+        float dot = 0.f;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) dot = fmaf(Gs[i * DMAX + c], Vs[j * DMAX + c], dot);
+        return dot;
+    };
+    // ---- A1 ----
+    if (tid < t) {
+        const int i = tid, ri = region_of(i), iy = i / ww, ix = i % ww;
+        float* row = P + i * tp;
+        float q[DMAX];
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) q[c] = Qs[i * DMAX + c];
+        float mx = -INFINITY;
+        for (int j = 0; j < t; ++j) {   // exactly attn_core_kernel's score(i, j)
+            float dot = 0.f;
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c) dot = fmaf(q[c], Ks[j * DMAX + c], dot);
+            float sc = dot * scale + tab[(j / ww - iy + wh - 1) * tw + (j % ww - ix + ww - 1)];
+            if (shift && region_of(j) != ri) sc = -1e10f;
+            row[j] = sc;
+            mx = fmaxf(mx, sc);
+        }
+        float l = 0.f;
+        for (int j = 0; j < t; ++j) { const float e = expf(row[j] - mx); row[j] = e; l += e; }
+        const float inv = 1.0f / l;
+        float D = 0.f;
+        for (int j = 0; j < t; ++j) { const float pj = row[j] * inv; row[j] = pj; D = fmaf(pj, dP(i, j), D); }
+        Drow[i] = D;
+    }
+    __syncthreads();
+    // ---- B1 ----
+    if (tid < t) {
+        const int j = tid;
+        float dv[DMAX];
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) dv[c] = 0.f;
+        for (int i = 0; i < t; ++i) {
+            const float pij = P[i * tp + j];
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c) dv[c] = fmaf(pij, Gs[i * DMAX + c], dv[c]);
+        }
+        const int64_t o = token_of(j) * ld + head * d;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c)
+            if (c < d) pr.dV[o + c] = dv[c];
+    }
+    __syncthreads();
+    // ---- A2 ----
+    if (tid < t) {
+        const int i = tid;
+        float* row = P + i * tp;
+        const float D = Drow[i];
+        float dq[DMAX];
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) dq[c] = 0.f;
+        for (int j = 0; j < t; ++j) {
+            const float ds = row[j] * (dP(i, j) - D);
+            row[j] = ds;
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c) dq[c] = fmaf(ds, Ks[j * DMAX + c], dq[c]);
+        }
+        const int64_t o = token_of(i) * ld + head * d;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c)
+            if (c < d) pr.dQ[o + c] = dq[c] * scale;
+    }
+    __syncthreads();
+    // ---- B2 ----
+    if (tid < t) {
+        const int j = tid;
+        float dk[DMAX];
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c) dk[c] = 0.f;
+        for (int i = 0; i < t; ++i) {
+            const float ds = P[i * tp + j];
+#pragma unroll
+            for (int c = 0; c < DMAX; ++c) dk[c] = fmaf(ds, Qs[i * DMAX + c], dk[c]);
+        }
+        const int64_t o = token_of(j) * ld + head * d;
+#pragma unroll
+        for (int c = 0; c < DMAX; ++c)
+            if (c < d) pr.dK[o + c] = dk[c] * scale;
+    }
+    // ---- C ----
+    float* dt = pr.dtable_partial + ((int64_t)win * heads + head) * tsz;
+    for (int e = tid; e < tsz; e += blockDim.x) {
+        const int dy = e / tw - (wh - 1), dx = e % tw - (ww - 1);   // key - query
+        float acc = 0.f;
+        for (int i = 0; i < t; ++i) {
+            const int jy = i / ww + dy, jx = i % ww + dx;
+            if (jy < 0 || jy >= wh || jx < 0 || jx >= ww) continue;
+            acc += P[i * tp + jy * ww + jx];
+        }
+        dt[e] = acc;
+    }
+}
+
 template <int DMAX>
 int launch_attn_bwd_t(const AttnBwdBatch& batch, int nprob, int ld, int B, int H, int W, int wh, int ww, int heads, int d, int shift, hipStream_t stream) {
     const int t = wh * ww, tsz = (2 * wh - 1) * (2 * ww - 1);
-    const size_t lds = ((size_t)4 * t * DMAX + tsz + 3 * t) * sizeof(float);
-    if (lds > 160 * 1024) return fail(SWF_ERR_UNSUPPORTED, "attention backward tile (t=%d, d=%d) needs %zu B of LDS", t, d, lds);
-    if (lds > 64 * 1024) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<DMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(attn_bwd): %s", hipGetErrorString(e));
-    }
     const int threads = cdiv(t, 64) * 64;
     if (threads > 1024) return fail(SWF_ERR_UNSUPPORTED, "attention backward: window of %d tokens > 1024", t);
     dim3 grid(B * (H / wh) * (W / ww), heads, nprob);
-    hipLaunchKernelGGL(attn_bwd_kernel<DMAX>, grid, dim3(threads), lds, stream, batch, ld, B, H, W, wh, ww, heads, d, shift, 1.0f / sqrtf((float)d));
-    return check_launch("attn_bwd");
+    const float scale = 1.0f / sqrtf((float)d);
+    const size_t lds_res = ((size_t)4 * t * DMAX + tsz + (size_t)t * (t + 1) + t) * sizeof(float);
+    if (lds_res <= 96 * 1024) {   // the probability tile stays in LDS (8 x 8 and 7 x 7 windows at every head width)
+        if (lds_res > 64 * 1024) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kernel<DMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_res);
+            if (e != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(attn_bwd): %s", hipGetErrorString(e));
+        }
+        hipLaunchKernelGGL(attn_bwd_kernel<DMAX>, grid, dim3(threads), lds_res, stream, batch, ld, B, H, W, wh, ww, heads, d, shift, scale);
+        return check_launch("attn_bwd");
+    }
+    const size_t lds = ((size_t)4 * t * DMAX + tsz + 3 * t) * sizeof(float);
+    if (lds > 160 * 1024) return fail(SWF_ERR_UNSUPPORTED, "attention backward tile (t=%d, d=%d) needs %zu B of LDS", t, d, lds);
+    if (lds > 64 * 1024) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_recompute_kernel<DMAX>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return fail(SWF_ERR_HIP, "hipFuncSetAttribute(attn_bwd): %s", hipGetErrorString(e));
+    }
+    hipLaunchKernelGGL(attn_bwd_recompute_kernel<DMAX>, grid, dim3(threads), lds, stream, batch, ld, B, H, W, wh, ww, heads, d, shift, scale);
+    return check_launch("attn_bwd (recompute)");
 }
 
 int launch_attn_bwd(const AttnBwdBatch& batch, int nprob, int ld, int B, int H, int W, int wh, int ww, int heads, int d, int shift, hipStream_t stream) {

@@ -24,6 +24,7 @@ _CASES = [  # C, heads, d, win, hidden, (B,H,W), shift, cross, dual
     (12, 4, 3, 7, 24, (1, 14, 14), True, True, True),         # 7x7 windows
     (16, 2, 8, 4, 40, (2, 8, 8), True, False, False),         # single-path block
     (48, 8, 6, 8, 192, (1, 8, 8), True, True, True),          # one window per map: the shift mask covers most of the score tile
+    (8, 2, 4, 16, 16, (1, 16, 32), True, True, True),         # 16x16 windows: the probability tile does not fit in LDS (recompute kernel)
 ]
 
 
