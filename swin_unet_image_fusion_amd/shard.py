@@ -72,8 +72,9 @@ def concurrent_streams(device, n: int, avoid=(), candidates: int = 12):
         one = min(_spin_ms([probe], cycles) for _ in range(3))
 
     def overlap(a, b) -> bool:
+        # single and pair timed back to back (the spin counts shader clocks: its wall time moves with the clock), best of three
         _spin_ms([a, b], cycles)
-        return min(_spin_ms([a, b], cycles) for _ in range(2)) < 1.5 * one
+        return min(_spin_ms([a, b], cycles) / max(_spin_ms([a], cycles), 1e-6) for _ in range(3)) < 1.5
 
     chosen = []
     pool = [probe] + [torch.cuda.Stream(device=device) for _ in range(candidates - 1)]

@@ -515,6 +515,25 @@ def test_pipelined_gather_on_a_one_rank_rccl_group():
             dist.destroy_process_group()
 
 
+def test_concurrent_streams_really_overlap():
+    """shard.concurrent_streams: the streams it returns run spin kernels side by side (one spin time for all of them), pairs of them
+    too, and none of them shares a hardware queue with the caller's stream."""
+    from swin_unet_image_fusion_amd.shard import _spin_ms, concurrent_streams
+    dev = torch.device(DEV)
+    cur = torch.cuda.current_stream(dev)
+    ss = concurrent_streams(dev, 3, avoid=[cur])
+    assert len(ss) >= 2 and len({s.cuda_stream for s in ss}) == len(ss)
+    cycles = 400_000
+    one = min(_spin_ms([ss[0]], cycles) for _ in range(3))
+    while one < 0.3 and cycles < 1 << 30:
+        cycles *= 2
+        one = min(_spin_ms([ss[0]], cycles) for _ in range(3))
+    ratio = lambda group: min(_spin_ms(group, cycles) / max(_spin_ms(group[:1], cycles), 1e-6) for _ in range(3))
+    assert ratio(ss) < 1.5, ratio(ss)
+    assert ratio([ss[0], cur]) < 1.5 and ratio([ss[-1], cur]) < 1.5
+    assert ratio([ss[0], ss[0]]) > 1.7          # (the measurement does see a shared queue: the same stream twice runs in order)
+
+
 @pytest.mark.parametrize("lanes", [2, 3])
 @pytest.mark.parametrize("collective", [False, True], ids=["local", "one_rank_rccl"])
 def test_steps_in_flight_keep_their_own_results(collective, lanes):
