@@ -71,7 +71,7 @@ __global__ __launch_bounds__(256) void bwd_dx_kernel(const float* __restrict__ d
         }
 }
 
-// partial[chunk][N][K] = sum over the chunk's tokens of dY[m][n] X[m][k]
+// partial[chunk] = { [N][K]: sum over the chunk's tokens of dY[m][n] X[m][k];  [N]: column sums of dY (the bias gradient) }
 __global__ __launch_bounds__(256) void bwd_dw_kernel(const float* __restrict__ dY, const float* __restrict__ X, float* __restrict__ partial,
                                                       int M, int N, int K) {
     __shared__ float As[16][65];
@@ -80,6 +80,7 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const float* __restrict__ d
     const int mlo = chunk * kChunk, mhi = min(M, mlo + kChunk);
     const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
     float acc[4][4] = {};
+    float bsum = 0.f;   // threads 0..63 of the k-tile-0 workgroups: column n0 + tid of dY
     for (int m0 = mlo; m0 < mhi; m0 += 16) {
         for (int e = tid; e < 16 * 64; e += 256) {
             const int r = e >> 6, c = e & 63;
@@ -88,6 +89,10 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const float* __restrict__ d
             Bs[r][c] = (live && k0 + c < K) ? X[(int64_t)(m0 + r) * K + k0 + c] : 0.f;
         }
         __syncthreads();
+        if (blockIdx.x == 0 && tid < 64) {
+#pragma unroll
+            for (int m = 0; m < 16; ++m) bsum += As[m][tid];
+        }
 #pragma unroll
         for (int m = 0; m < 16; ++m) {
             float a[4], b[4];
@@ -100,7 +105,7 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const float* __restrict__ d
         }
         __syncthreads();
     }
-    float* p = partial + (int64_t)chunk * N * K;
+    float* p = partial + (int64_t)chunk * N * (K + 1);
 #pragma unroll
     for (int i = 0; i < 4; ++i)
 #pragma unroll
@@ -108,6 +113,7 @@ __global__ __launch_bounds__(256) void bwd_dw_kernel(const float* __restrict__ d
             const int n = n0 + 4 * ty + i, k = k0 + 4 * tx + j;
             if (n < N && k < K) p[(int64_t)n * K + k] = acc[i][j];
         }
+    if (blockIdx.x == 0 && tid < 64 && n0 + tid < N) p[(int64_t)N * K + n0 + tid] = bsum;
 }
 
 // partial[chunk][N] = column sums of dY over the chunk's tokens.  The block covers NP = min(256, pow2 >= N) columns with 256 / NP row
@@ -137,6 +143,16 @@ __global__ __launch_bounds__(256) void reduce_rows_kernel(const float* __restric
     float s = 0.f;
     for (int r = r0; r < r1; ++r) s += partial[(int64_t)r * count + i];
     out[(int64_t)blockIdx.y * count + i] = s;
+}
+// the last level with two destinations: elements [0, count_a) -> out_a, the rest -> out_b (either may be NULL)
+__global__ __launch_bounds__(256) void reduce_rows_split_kernel(const float* __restrict__ partial, float* __restrict__ out_a, int64_t count_a,
+                                                                 float* __restrict__ out_b, int64_t count, int rows) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= count) return;
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += partial[(int64_t)r * count + i];
+    if (i < count_a) { if (out_a) out_a[i] = s; }
+    else if (out_b) out_b[i - count_a] = s;
 }
 
 __global__ __launch_bounds__(256) void elu_bwd_kernel(float* __restrict__ dh, const float* __restrict__ h, int64_t count) {
@@ -577,7 +593,8 @@ int64_t tree_rows(int64_t rows) {
     while (rows > kGroup) { rows = cdiv64(rows, kGroup); t += rows; }
     return t;
 }
-int reduce_rows(float* partial, float* out, int64_t count, int64_t rows, hipStream_t st) {
+// out_b != NULL or count_a < count: the summed vector is split, [0, count_a) -> out, the rest -> out_b
+int reduce_rows(float* partial, float* out, int64_t count, int64_t rows, hipStream_t st, int64_t count_a = -1, float* out_b = nullptr) {
     float* src = partial;
     while (rows > kGroup) {
         const int64_t g = cdiv64(rows, kGroup);
@@ -586,7 +603,10 @@ int reduce_rows(float* partial, float* out, int64_t count, int64_t rows, hipStre
         SWF_TRY(check_launch("reduce_rows level"));
         src = dst; rows = g;
     }
-    hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv64(count, 256), 1), dim3(256), 0, st, src, out, count, (int)rows);
+    if (count_a >= 0)
+        hipLaunchKernelGGL(reduce_rows_split_kernel, dim3((unsigned)cdiv64(count, 256)), dim3(256), 0, st, src, out, count_a, out_b, count, (int)rows);
+    else
+        hipLaunchKernelGGL(reduce_rows_kernel, dim3((unsigned)cdiv64(count, 256), 1), dim3(256), 0, st, src, out, count, (int)rows);
     return check_launch("reduce_rows");
 }
 int colsum_np(int N) { int np = 1; while (np < N && np < 256) np *= 2; return np; }
@@ -597,18 +617,12 @@ int colsum(const float* dY, float* partial, int64_t M, int N, hipStream_t st) {
 }
 // dW [N][K] (and db [N] when asked) of a linear layer y = x W^T + b from dY [M][N] and X [M][K]; scratch: tree_rows(chunks) * N * (K + 1) floats
 int dw(const float* dY, const float* X, float* dW, float* db, int64_t M, int N, int K, float* scratch, hipStream_t st) {
+    if (!dW && !db) return SWF_OK;
     const int ch = chunks_of(M);
-    if (dW) {
-        hipLaunchKernelGGL(bwd_dw_kernel, dim3(cdiv(K, 64), cdiv(N, 64), ch), dim3(256), 0, st, dY, X, scratch, (int)M, N, K);
-        SWF_TRY(check_launch("bwd_dw"));
-        SWF_TRY(reduce_rows(scratch, dW, (int64_t)N * K, ch, st));
-    }
-    if (db) {
-        float* ps = scratch + tree_rows(ch) * N * K;
-        SWF_TRY(colsum(dY, ps, M, N, st));
-        SWF_TRY(reduce_rows(ps, db, (int64_t)N, ch, st));
-    }
-    return SWF_OK;
+    // one pass over dY and X for both: the weight-gradient workgroups of k tile 0 also sum their dY columns (the bias gradient)
+    hipLaunchKernelGGL(bwd_dw_kernel, dim3(cdiv(K, 64), cdiv(N, 64), ch), dim3(256), 0, st, dY, X, scratch, (int)M, N, K);
+    SWF_TRY(check_launch("bwd_dw"));
+    return reduce_rows(scratch, dW, (int64_t)N * (K + 1), ch, st, (int64_t)N * K, db);
 }
 int ln_blocks(int64_t M) { return (int)cdiv64(M, 4 * kLnRows); }
 // dx = dres + LayerNorm backward of dy; d gamma / d beta (either may be NULL); scratch: tree_rows(ln_blocks * 4) * 2 * C + 2 * C floats
