@@ -397,6 +397,7 @@ def main():
                                      if args.precision == "fast" else "exact fp32 (f32-input MFMA)",
                        "residual_stream": "fp32", "hip_graph": runner.graph_active, "graph_equals_eager": graph_equals_eager,
                        "steps_in_flight": runner.in_flight if runner.graph_active else 1,
+                       "kernel_schedule": getattr(model, "schedule", None),
                        "one_step_at_a_time": None if serial_ms is None else
                        {"ms_per_step": round(serial_ms, 4), "pairs_per_s": round(args.batch * world / serial_ms * 1e3, 1)},
                        "collective": "rccl all_gather_into_tensor of the fused output per step, overlapped with the next steps' forwards" if world > 1 else

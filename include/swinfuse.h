@@ -88,11 +88,18 @@ int swf_window_attention_fwd_prec(const swf_attn_desc* desc, int32_t precision, 
 size_t swf_window_attention_workspace_bytes(const swf_attn_desc* desc, int32_t B, int32_t H, int32_t W);
 
 /* ---- BasicBlock (a005_BasicBlock.py:127-145) and its two halves ---------------------------- */
+/* Which kernel shapes the fast tier picks where it has a choice (same arithmetic, results differ in the last bits):
+ * LATENCY (default): shortest single forward — eight waves per window at level 2, 32-token MLP tiles at level 3;
+ * THROUGHPUT: least CU-time per forward, for callers that keep several forwards in flight on separate streams
+ * (ShardedFusion lanes) — four waves per window (two windows per CU), 64-token MLP tiles. */
+typedef enum swf_schedule { SWF_SCHED_LATENCY = 0, SWF_SCHED_THROUGHPUT = 1 } swf_schedule;
+
 typedef struct swf_block_desc {
     swf_attn_desc attn;
     int32_t hidden;        /* mlp_hidden_dims */
     int32_t cross;         /* use_cross_attr: x'=WA_x(q=x,k=y,v=y), y'=WA_y(q=y,k=x,v=x) (a002_AutoPathWinAtt.py:67-82) */
     int32_t precision;     /* swf_precision */
+    int32_t schedule;      /* swf_schedule */
 } swf_block_desc;
 
 typedef struct swf_block_stream_params {   /* one modality stream of one BasicBlock */
@@ -282,6 +289,7 @@ typedef struct swf_model_desc {
     int32_t win_h, win_w, merge_h, merge_w;
     int32_t head_ksize;                  /* final_conv_layer_kernel_size */
     int32_t precision;                   /* swf_precision */
+    int32_t schedule;                    /* swf_schedule */
 } swf_model_desc;
 
 /* The weights live in ONE fp32 device arena whose layout the library defines.  Parameter i has

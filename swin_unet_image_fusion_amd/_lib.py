@@ -41,7 +41,7 @@ class AttnParams(C.Structure):
 
 
 class BlockDesc(C.Structure):
-    _fields_ = [("attn", AttnDesc), ("hidden", C.c_int32), ("cross", C.c_int32), ("precision", C.c_int32)]
+    _fields_ = [("attn", AttnDesc), ("hidden", C.c_int32), ("cross", C.c_int32), ("precision", C.c_int32), ("schedule", C.c_int32)]
 
 
 class BlockStreamParams(C.Structure):
@@ -66,7 +66,7 @@ class ModelDesc(C.Structure):
     _fields_ = [("levels", C.c_int32), ("in_dims", C.c_int32 * SWF_MAX_LEVELS), ("out_dims", C.c_int32 * SWF_MAX_LEVELS),
                 ("heads", C.c_int32), ("head_dim", C.c_int32 * SWF_MAX_LEVELS), ("mlp_ratio", C.c_int32),
                 ("win_h", C.c_int32), ("win_w", C.c_int32), ("merge_h", C.c_int32), ("merge_w", C.c_int32),
-                ("head_ksize", C.c_int32), ("precision", C.c_int32)]
+                ("head_ksize", C.c_int32), ("precision", C.c_int32), ("schedule", C.c_int32)]
 
 
 P = C.POINTER

@@ -13,6 +13,7 @@ struct MlpFusedDesc {
     const float* b1[2]; const float* b2[2];
     float* scratch; int64_t scratch_floats;         // nstream * mlp_fused_splits * M * C floats when splits > 1
     int M, C, HID;
+    int schedule;                                   // swf_schedule: THROUGHPUT takes 64-token tiles where LATENCY takes 32 (C = 192)
     // optional (all or none): LayerNorm of the finished rows with these parameters — the next block's LN1 — written as split
     // planes [M][C] by the reduce kernel (hidden splits > 1) or by the fused kernel's own epilogue (unsplit).
     const float* ln_gamma[2]; const float* ln_beta[2]; bf16_raw* ln_hi[2]; bf16_raw* ln_lo[2];

@@ -639,7 +639,9 @@ int launch_mlp_fused(const MlpFusedDesc& d, int nstream, hipStream_t stream) {
     }
     a.M = d.M; a.HID = d.HID;
     a.splits = mlp_fused_splits(d.C, d.HID);
-    const bool wide = mlp_wide(d.C, d.HID), tok32 = mlp_tok32(d.C, d.HID);
+    // (mlp_fused_splits is 1 for the C = 192 shapes either way: the 64-token kernel then walks all six 128-wide chunks itself —
+    //  half the workgroups, each streaming the weights once: less CU-time, longer launch)
+    const bool wide = mlp_wide(d.C, d.HID), tok32 = mlp_tok32(d.C, d.HID) && d.schedule != SWF_SCHED_THROUGHPUT;
     a.nchunks = d.HID / (wide ? 256 : tok32 ? 192 : 128) / a.splits;
     a.scratch = d.scratch;
     if (d.ln_hi[0])

@@ -1309,7 +1309,8 @@ int launch_win96(const swf_block_desc& d, const void* packed_x, const void* pack
     static const bool no_x8 = [] { const char* e = debug_env("SWF_WIN96X8"); return e && e[0] == '0'; }();   // A/B switch (tools)
     // Maps of up to 16 windows (32 x 32 tokens: B=16 256x256 has 256 windows for 256 CUs) take eight waves per window
     // (window96x8_kernel).  The rule looks at the map, never at the batch: batch shards stay bit-identical.
-    if (!no_x8 && (H / wsd) * (W / wsd) <= 16) {
+    // (THROUGHPUT schedule: four waves per window, two windows per CU hide each other's phase latencies)
+    if (!no_x8 && d.schedule != SWF_SCHED_THROUGHPUT && (H / wsd) * (W / wsd) <= 16) {
         const int gx = std::min(nwin, num_cus96());
         if (wsd == 8) return d.hidden == 384 ? launch96x8_t<384, 8>(a, gx, stream) : launch96x8_t<192, 8>(a, gx, stream);
         return d.hidden == 384 ? launch96x8_t<384, 7>(a, gx, stream) : launch96x8_t<192, 7>(a, gx, stream);

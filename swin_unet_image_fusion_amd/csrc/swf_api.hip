@@ -393,7 +393,7 @@ static int deep_block_impl(const swf_block_desc* desc, const swf_block_stream_pa
             md.w1_hi[s] = wv[s].w1f_hi; md.w1_lo[s] = wv[s].w1f_lo; md.w2_hi[s] = wv[s].w2f_hi; md.w2_lo[s] = wv[s].w2f_lo;
             md.b1[s] = pp[s]->fc1.bias; md.b2[s] = pp[s]->fc2.bias;
         }
-        md.scratch = sk; md.scratch_floats = sk_floats; md.M = (int)N; md.C = C; md.HID = hid;
+        md.scratch = sk; md.scratch_floats = sk_floats; md.M = (int)N; md.C = C; md.HID = hid; md.schedule = desc->schedule;
         const bool ln_next = next_p && ln1_ready && next_p[0] && (nstream == 1 || next_p[1]) && mlp_fused_writes_ln(C, hid);
         if (ln_next)
             for (int s = 0; s < nstream; ++s) {
@@ -860,6 +860,7 @@ static swf_block_desc level_block_desc(const swf_model_desc* d, int lvl, bool en
     b.hidden = (encoder ? d->out_dims[lvl] : d->in_dims[lvl]) * d->mlp_ratio;
     b.cross = 0;
     b.precision = d->precision;
+    b.schedule = d->schedule;
     return b;
 }
 

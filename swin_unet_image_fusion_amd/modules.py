@@ -908,7 +908,9 @@ class MyModel(_FwdAlias, nn.Module):
     `forward(in_x, in_y)` is ONE call into the C-ABI (`swf_model_forward`): the parameters are
     copied once into a flat device arena whose layout the library defines by state_dict key
     (`swf_model_param_info`), and the whole U-Net runs from that arena on the current stream.
-    `precision` ('fast' | 'fp32') selects the arithmetic mode (include/swinfuse.h swf_precision).
+    `precision` ('fast' | 'fp32') selects the arithmetic mode (include/swinfuse.h swf_precision); `schedule` ('latency' |
+    'throughput', swf_schedule) the kernel shapes of the fast tier where it has a choice: 'latency' for one forward at a time,
+    'throughput' for several forwards in flight (shard.ShardedFusion sets it for its lanes).
     """
 
     def __init__(self, window_size: tuple, merging_size: tuple, in_dims_list: list, out_dims_list: list,
@@ -928,6 +930,7 @@ class MyModel(_FwdAlias, nn.Module):
         self.feature_shape_recorder, self.padding_size_recorder = StateRecorder(), StateRecorder()
         self.patch_merging_size_recorder, self.u_net_intermediate_result_recorder = StateRecorder(), StateRecorder()
         self.precision = "fast"
+        self.schedule = "latency"
         self._arena: Optional[Tensor] = None
         self._arena_key = None
         self._packed: Optional[Tensor] = None
@@ -976,6 +979,9 @@ class MyModel(_FwdAlias, nn.Module):
         d.merge_h, d.merge_w = self.merging_size
         d.head_ksize = self.final_layer_conv_kernel_size
         d.precision = _precision_code(self.precision)
+        if self.schedule not in ("latency", "throughput"):
+            raise ValueError(f"schedule must be 'latency' or 'throughput', got {self.schedule!r}")
+        d.schedule = 1 if self.schedule == "throughput" else 0
         return d
 
     def refresh_weights(self) -> None:
@@ -993,7 +999,7 @@ class MyModel(_FwdAlias, nn.Module):
     def graph_key(self):
         """Everything a captured forward depends on besides the input shape: the weights epoch, the arithmetic mode and
         the addresses of the arena / packed images (None before the first forward)."""
-        return (self.weights_epoch, self.precision, None if self._arena is None else self._arena.data_ptr(),
+        return (self.weights_epoch, self.precision, self.schedule, None if self._arena is None else self._arena.data_ptr(),
                 None if self._packed is None else self._packed.data_ptr())
 
     def param_layout(self):

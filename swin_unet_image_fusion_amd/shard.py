@@ -156,6 +156,10 @@ class ShardedFusion:
         self.forward_fn = forward_fn or (lambda a, b: model(a, b))
         self.use_graph = use_graph
         self.in_flight = in_flight
+        if in_flight > 1 and use_graph and getattr(model, "schedule", None) == "latency":
+            # several forwards in flight: the kernel shapes with the least CU-time per forward (the model's eager forwards follow,
+            # so replay and eager stay bit-identical); set model.schedule yourself afterwards to override
+            model.schedule = "throughput"
         self.graph_active = False
         self._lanes = [_Lane() for _ in range(in_flight)]
         self._lane_streams_ready = False

@@ -273,6 +273,33 @@ def test_model_golden(name, precision):
     print(f"{name} [{precision}] rel-L2={l2:.2e} max-rel={mx:.2e}")
 
 
+@pytest.mark.parametrize("name", [n for n in _MODEL_CASES if any(k in n for k in ("win8_256", "win7_224", "win7_200", "win8_b2", "win8_512"))])
+def test_model_golden_throughput_schedule(name):
+    """model.schedule = 'throughput' (what ShardedFusion's lanes run): the kernel shapes chosen for several forwards in flight — four
+    waves per window at level 2, 64-token MLP tiles at level 3 — against the reference goldens at the fast tier's gates; the batch
+    dimension stays separable in this schedule too (shards of a batch are bit-identical rows)."""
+    meta, arr = G.load(name)
+    cfg = CONFIGS[meta["config"]]
+    m = MyModel(**cfg.model_kwargs(_elu())).eval()
+    load_recipe_into(m, seed=meta["weight_seed"], flavor=meta["flavor"])
+    m.to(DEV)
+    m.schedule = "throughput"
+    ir, vis = (t.to(DEV) for t in G.model_inputs(meta))
+    out = m(ir, vis)
+    l2, mx = _close(out, arr["expected"], TOL_FAST_L2, TOL_FAST_MAX)
+    print(f"{name} [fast, throughput] rel-L2={l2:.2e} max-rel={mx:.2e}")
+    ir4, vis4 = torch.cat([ir, vis, ir, vis]), torch.cat([vis, ir, vis, ir])
+    full = m(ir4, vis4)
+    assert torch.equal(full[:ir.shape[0]], out)
+    assert torch.equal(m(ir4[2 * ir.shape[0]:], vis4[2 * ir.shape[0]:]), full[2 * ir.shape[0]:])
+    m.schedule = "latency"
+    lat = m(ir, vis)
+    _close(lat, arr["expected"], TOL_FAST_L2, TOL_FAST_MAX)
+    with pytest.raises(ValueError):
+        m.schedule = "fastest"
+        m(ir, vis)
+
+
 def test_model_error_behaviour():
     m = MyModel(**CONFIGS["win8"].model_kwargs(_elu())).eval().to(DEV)
     ir, vis = (torch.from_numpy(a).to(DEV) for a in synthetic_pair(1, 128, 128))
