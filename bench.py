@@ -368,15 +368,23 @@ def main():
         elapsed = float(t.item())
     assert fused.shape[0] == args.batch * world and bool(torch.isfinite(fused).all())
     # the same steps one at a time (each waited for before the next is enqueued): the latency of one step, for the record
+    # (its own one-lane runner in the latency schedule: what a caller gets who waits for every step before enqueueing the next)
     serial_ms = None
-    if not dry and runner.in_flight > 1:
+    if not dry and runner.in_flight > 1 and runner.graph_active:
+        lanes_schedule = model.schedule
+        model.schedule = "latency"
+        single = ShardedFusion(model, world_size=world, rank=rank, use_graph=True, in_flight=1, force_collective=runner.force_collective)
+        for _ in range(2):
+            single.step(ir, vis)
         n_serial = min(args.steps, 20)
         sync()
         t1 = time.perf_counter()
         for _ in range(n_serial):
-            fused = runner.step(ir, vis)
+            single.step(ir, vis)
         sync()
         serial_ms = (time.perf_counter() - t1) / n_serial * 1e3
+        del single
+        model.schedule = lanes_schedule
     # the timed path is the hipGraph replay: check it against one eager forward of the same inputs before reporting it
     graph_equals_eager = None
     if runner.graph_active:
