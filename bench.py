@@ -370,7 +370,7 @@ def main():
     # the same steps one at a time (each waited for before the next is enqueued): the latency of one step, for the record
     # (its own one-lane runner in the latency schedule: what a caller gets who waits for every step before enqueueing the next)
     serial_ms = None
-    if not dry and runner.in_flight > 1 and runner.graph_active:
+    if not dry and world == 1 and runner.in_flight > 1 and runner.graph_active:   # (one GPU only: how many lanes a rank found is its own business, and extra collectives on some ranks would hang the job)
         lanes_schedule = model.schedule
         model.schedule = "latency"
         single = ShardedFusion(model, world_size=world, rank=rank, use_graph=True, in_flight=1, force_collective=runner.force_collective)
