@@ -215,7 +215,10 @@ class ShardedFusion:
     def _pick_lane_streams(self, device):
         """Overlapped lanes need streams on distinct hardware queues (concurrent_streams); with fewer distinct queues than lanes the
         runner keeps as many lanes as it found queues for."""
-        got = concurrent_streams(device, self.in_flight, avoid=[torch.cuda.current_stream(device)])
+        # A lane may share its hardware queue with the caller's stream: what the caller puts there are waits for the OLDEST step in
+        # flight, and everything queued in front of such a wait is work that finishes after that step anyway (measured: four lanes
+        # on the four queues 9 025-9 041 pairs/s, three lanes that leave the caller's queue alone 8 635, same box).
+        got = concurrent_streams(device, self.in_flight)
         if not got:
             got = [torch.cuda.Stream(device=device)]
         if len(got) < self.in_flight:
