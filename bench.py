@@ -288,6 +288,19 @@ def baseline_config_label(args, cfg, world):
     return "not a BASELINE config"
 
 
+def _rccl_options():
+    """RCCL's stream at high priority: its own hardware queue (HIP keeps a queue pool per priority), so the all-gather never sits in a
+    queue behind a lane's graph, and its kernel is dispatched ahead of compute when it becomes ready (SWF_RCCL_PRIORITY=0: default stream)."""
+    if os.environ.get("SWF_RCCL_PRIORITY", "1") == "0":
+        return None
+    try:
+        opts = dist.ProcessGroupNCCL.Options()
+        opts.is_high_priority_stream = True
+        return opts
+    except Exception:   # a torch build without the option: the default stream
+        return None
+
+
 def main():
     args = parse()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -306,13 +319,13 @@ def main():
     if world == 1 and args.force_collective and not dry:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", str(29500 + os.getpid() % 400))
-        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=_rccl_options())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if dry:
             dist.init_process_group("gloo")
         else:
-            dist.init_process_group("nccl", device_id=dev)   # RCCL
+            dist.init_process_group("nccl", device_id=dev, pg_options=_rccl_options())   # RCCL
 
     from swin_unet_image_fusion_amd import CONFIGS, MyModel, load_recipe_into, synthetic_pair
     from swin_unet_image_fusion_amd.shard import ShardedFusion
