@@ -100,7 +100,7 @@ class _DeferredGather(GatherHandle):
             return
         r, k = self._runner, self._slot
         with torch.cuda.stream(self._lane_stream):     # RCCL's stream waits for the lane's staging copy, not for the caller's stream
-            work = dist.all_gather_into_tensor(r._gathered[k], r._stage[k], group=r.group, async_op=True)
+            work = r._all_gather(k)
         r._slot_work[k] = self._work = work
         self._issued = True
 
@@ -288,15 +288,19 @@ class ShardedFusion:
             self._slot_work[k].wait()
         return k
 
+    def _all_gather(self, k: int):
+        """The collective of ring slot k: RCCL's all_gather_into_tensor; the list form under gloo (CPU tensors, and GPU tensors in the
+        two-rank test that shares one GPU)."""
+        if self._stage[k].is_cuda and dist.get_backend(self.group) == "nccl":
+            return dist.all_gather_into_tensor(self._gathered[k], self._stage[k], group=self.group, async_op=True)
+        return dist.all_gather(list(self._gathered[k].chunk(self.world_size, dim=0)), self._stage[k], group=self.group, async_op=True)
+
     def gather_async(self, local_out: torch.Tensor) -> GatherHandle:
         if self.world_size == 1 and not self.force_collective:
             return GatherHandle(local_out)
         k = self._next_slot(local_out)
         self._stage[k].copy_(local_out)   # the collective reads a buffer nothing rewrites while it is in flight
-        if local_out.is_cuda:
-            work = dist.all_gather_into_tensor(self._gathered[k], self._stage[k], group=self.group, async_op=True)
-        else:   # gloo
-            work = dist.all_gather(list(self._gathered[k].chunk(self.world_size, dim=0)), self._stage[k], group=self.group, async_op=True)
+        work = self._all_gather(k)
         self._slot_work[k] = work
         return GatherHandle(self._gathered[k], work)
 
