@@ -136,6 +136,11 @@ def level0_block_roofline(model, batch, size, precision, iters=20, height=0, wid
 MFMA_PEAK_FLOPS = 2.5e15    # MI355X_MICROARCH.md: dense bf16 / f16 MFMA peak
 # kernel symbols of one BasicBlock per level at the default dims with 8x8 / 7x7 windows on 256x256 inputs;
 # other shapes dispatch differently (profiles/*_forward_timeline*.txt name what ran)
+PMC_LEVELS_THROUGHPUT_FILE = "r03c_pmc_levels_throughput.json"   # levels 2 and 3 in the throughput schedule (the other levels' kernels are the same)
+LEVEL_KERNELS_THROUGHPUT = {
+    2: "window96_kernel<HID, WS> (four waves per window, two windows per CU)",
+    3: "qkv_attn_kernel<192, WS> + mlp_fused_kernel<192, 4, 64> (64-token tiles, the whole hidden range per workgroup)",
+}
 LEVEL_KERNELS_WIN8 = {
     0: "window24_kernel<HID, WS>", 1: "window48_kernel<HID, WS>", 2: "window96x8_kernel<HID, WS> (maps of > 16 windows: window96_kernel)",
     3: "qkv_attn_kernel<192, WS> + mlp_fused_kernel<192, 4> (+ mlp_reduce_ln_kernel when the hidden dim is split)",
@@ -180,9 +185,19 @@ def level_rooflines(model, ir, vis, step_ms, iters=5):
     # of the named file, collected on the build it names, for the default workload's encoder widths only)
     pmc = None
     pj = os.path.join(REPO, "profiles", PMC_LEVELS_FILE)
+    throughput = getattr(model, "schedule", "latency") == "throughput"
     if os.path.exists(pj) and b == 16 and h == 256 and w == 256 and wh == 8 and n == 5:
         with open(pj) as f:
             pmc = json.load(f)
+        pmc["file"] = {str(k): PMC_LEVELS_FILE for k in range(n)}
+        pt = os.path.join(REPO, "profiles", PMC_LEVELS_THROUGHPUT_FILE)
+        if throughput and os.path.exists(pt):
+            with open(pt) as f:
+                thr = json.load(f)
+            for k, v in thr.get("levels", {}).items():
+                if v:
+                    pmc["levels"][k] = v
+                    pmc["file"][k] = PMC_LEVELS_THROUGHPUT_FILE
     hh, wd = h, w
     shapes = []
     for s in range(n):   # map of level s: merged (reflect-padded to the merge size), then padded to a multiple of the window
@@ -205,13 +220,14 @@ def level_rooflines(model, ir, vis, step_ms, iters=5):
             seg_i = 2 * lvl + 1 if side == "encoder" else 2 * n + 2 * k
             us = ms[seg_i] * 1e3 / 4
             entry = {"level": lvl, "side": side, "C": c, "hidden": hid, "tokens_per_stream": ntok, "us_per_block": round(us, 2),
-                     "kernels": LEVEL_KERNELS_WIN8.get(lvl, "see profiles/") if wh in (7, 8) and n == 5 else "see profiles/",
+                     "kernels": ((LEVEL_KERNELS_THROUGHPUT.get(lvl) if throughput else None) or LEVEL_KERNELS_WIN8.get(lvl, "see profiles/"))
+                     if wh in (7, 8) and n == 5 else "see profiles/",
                      "algorithmic_bytes": blk_bytes, "algorithmic_flops": blk_flops,
                      "frac_hbm": round(blk_bytes / (us * 1e-6) / (HBM_PEAK_GBS * 1e9), 4),
                      "frac_mfma": round(blk_flops / (us * 1e-6) / MFMA_PEAK_FLOPS, 4),
                      "frac_mfma_issued": round((blk_flops + 2 * lin_flops) / (us * 1e-6) / MFMA_PEAK_FLOPS, 4)}
             if pmc and side == "encoder" and str(lvl) in pmc.get("levels", {}):
-                entry["pmc"] = {"source": f"profiles/{PMC_LEVELS_FILE} (build {pmc.get('commit', '?')}; rocprofv3 --pmc, one block of the level in a loop)",
+                entry["pmc"] = {"source": f"profiles/{pmc['file'][str(lvl)]} (rocprofv3 --pmc, one block of the level in a loop)",
                                 "kernels": {k: {f: v[f] for f in ("us_under_pmc", "mfma_busy", "valu_active", "lds_conflict") if f in v}
                                             for k, v in pmc["levels"][str(lvl)].items() if "split_planes" not in k and "layernorm_vec" not in k}}
             if lvl == 0 and side == "encoder" and c == 24 and hid == 96 and wh == 8:

@@ -1,6 +1,6 @@
 """Launch one BasicBlock unit repeatedly (for rocprofv3 / PMC runs and A/B timing in one process).
 
-    python tools/profile_block.py --level 0 --iters 20 [--precision fast|fp32] [--shift 1] [--cross 1]
+    python tools/profile_block.py --level 0 --iters 20 [--precision fast|fp32] [--shift 1] [--cross 1] [--schedule throughput]
 """
 import argparse
 import ctypes as C
@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--precision", default="fast")
     ap.add_argument("--shift", type=int, default=1)
     ap.add_argument("--cross", type=int, default=1)
+    ap.add_argument("--schedule", default="latency", choices=["latency", "throughput"])
     a = ap.parse_args()
     entry.build()
     from swin_unet_image_fusion_amd import CONFIGS, MyModel, _lib as L, load_recipe_into
@@ -43,6 +44,7 @@ def main():
     ox, oy = torch.empty_like(x), torch.empty_like(y)
     lib = L.lib()
     desc = blk._desc(a.precision)
+    desc.schedule = 1 if a.schedule == "throughput" else 0
     px, py = blk._stream_params("x"), blk._stream_params("y")
     ws, wsn = _workspace(lib.swf_basic_block_workspace_bytes(C.byref(desc), a.batch, h, w), x.device)
     st = _stream(x.device)
