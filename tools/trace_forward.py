@@ -21,6 +21,7 @@ def run():
     load_recipe_into(model, seed=0)
     model.to("cuda:0")
     model.precision = "fast"
+    model.schedule = os.environ.get("TRACE_SCHEDULE", "latency")   # "throughput": the kernels ShardedFusion's lanes replay
     size = int(os.environ.get("TRACE_SIZE", "256"))
     ir, vis = synthetic_pair(int(os.environ.get("TRACE_BATCH", "16")), size, size)
     ir, vis = torch.from_numpy(ir).cuda(), torch.from_numpy(vis).cuda()
