@@ -322,6 +322,11 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    # rehearsal on a one-GPU box (tests/test_gpu_bench_two_ranks.py): every rank on device 0, gloo as the transport (RCCL cannot put
+    # two ranks on one device).  Everything else — lanes, deferred collectives, barriers, the MAX all-reduce — is the N > 1 path.
+    share_gpu = os.environ.get("SWF_BENCH_SHARE_GPU") == "1"
+    if share_gpu:
+        local = 0
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
     dry = args.dry_run
@@ -338,7 +343,7 @@ def main():
         dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=_rccl_options())
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if dry:
+        if dry or share_gpu:
             dist.init_process_group("gloo")
         else:
             dist.init_process_group("nccl", device_id=dev, pg_options=_rccl_options())   # RCCL
@@ -437,7 +442,8 @@ def main():
                        "kernel_schedule": getattr(model, "schedule", None),
                        "one_step_at_a_time": None if serial_ms is None else
                        {"ms_per_step": round(serial_ms, 4), "pairs_per_s": round(args.batch * world / serial_ms * 1e3, 1)},
-                       "collective": "rccl all_gather_into_tensor of the fused output per step, overlapped with the next steps' forwards" if world > 1 else
+                       "collective": ("gloo all_gather of GPU tensors (ranks share one GPU: rehearsal)" if share_gpu else
+                                      "rccl all_gather_into_tensor of the fused output per step, overlapped with the next steps' forwards") if world > 1 else
                                      ("one-rank rccl all_gather_into_tensor per step (rehearsal)" if args.force_collective else "none"),
                        "weights": "random-init (numpy PCG64 recipe, seed 0)"},
         }
