@@ -1079,6 +1079,10 @@ class MyModel(_FwdAlias, nn.Module):
         if in_x.shape != in_y.shape or in_x.shape[1] != self.in_dims_list[0]:
             raise ValueError(f"expected two (B,{self.in_dims_list[0]},H,W) tensors, got {tuple(in_x.shape)} and {tuple(in_y.shape)}")
         self.u_net_intermediate_result_recorder.delete_all()
+        if self._arena is not None:
+            # a differentiable forward is a training step: an optimizer is about to change the parameters in place, which nothing
+            # here could notice — drop the fused forward's weight arena now, the next no-grad forward (a016:202) rebuilds it
+            self.refresh_weights()
         x, y = in_x, in_y
         if not x.requires_grad:      # the module-level autograd Functions key on their inputs
             x, y = x.detach().requires_grad_(True), y.detach().requires_grad_(True)

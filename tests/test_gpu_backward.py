@@ -193,7 +193,11 @@ def test_training_mode_steps_vs_autograd_of_the_oracle(cfg_name, shape):
     m = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True)))
     load_recipe_into(m, seed=11, flavor="stress")
     sd = {k: v.detach().clone().requires_grad_(v.is_floating_point() and "running" not in k) for k, v in m.state_dict().items()}
-    m.to(DEV).train()
+    m.to(DEV).eval()
+    with torch.no_grad():      # a fused forward before the training steps: its weight arena holds the STARTING weights
+        m(*(torch.from_numpy(a).to(DEV) for a in synthetic_pair(b, h, w, seed_ir=60, seed_vis=70)))
+    assert m._arena is not None
+    m.train()
     lr, first = 1e-3, None
     for step in range(3):
         ir, vis = (torch.from_numpy(a) for a in synthetic_pair(b, h, w, seed_ir=61 + step, seed_vis=71 + step))
@@ -215,6 +219,18 @@ def test_training_mode_steps_vs_autograd_of_the_oracle(cfg_name, shape):
             for k, p in m.named_parameters():
                 p -= lr * p.grad
                 sd[k] -= lr * sd[k].grad
+    # a016:202: the evaluation forward after the training steps (fused, no grad) must run the UPDATED weights without a manual refresh
+    m.eval()
+    with torch.no_grad():
+        ev = m(ir.to(DEV), vis.to(DEV))
+    ev_ref = O.model_forward({k: v.detach() for k, v in sd.items()}, cfg, ir, vis)
+    assert float((ev.cpu() - ev_ref).abs().max() / ev_ref.abs().max()) <= 2e-3
+    fresh = MyModel(**cfg.model_kwargs(nn.ELU(inplace=True)))
+    fresh.load_state_dict(m.state_dict(), strict=True)
+    fresh.to(DEV).eval()
+    with torch.no_grad():
+        assert torch.equal(fresh(ir.to(DEV), vis.to(DEV)), ev)      # bit for bit what a model freshly loaded with the trained weights gives
+    m.train()
     got = m.state_dict()
     for k in ("final_layer.1.running_mean", "final_layer.1.running_var"):
         assert torch.allclose(got[k].cpu(), sd[k], rtol=2e-3, atol=1e-6), (k, got[k].cpu(), sd[k])
