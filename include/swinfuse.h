@@ -159,6 +159,24 @@ int swf_basic_block_bwd(const swf_block_desc* desc, const swf_block_stream_param
                         float* gx_in, float* gy_in, const swf_block_stream_grads* gpx, const swf_block_stream_grads* gpy,
                         int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream);
 
+/* The inner modules on their own under autograd (a caller that keeps the reference's BasicBlock and swaps only a001 / a003 / a004):
+ * exact fp32, forward intermediates recomputed, fixed-order sums.  Gradient pointers as above (NULL = not wanted).
+ * WindowAttention.forward (a001:448-474): q / k / v [B][H][W][C]; gq / gk / gv are three separate buffers — where one tensor was passed
+ * as more than one of q, k, v the caller adds them (torch.autograd does). */
+size_t swf_window_attention_bwd_workspace_bytes(const swf_attn_desc* desc, int32_t B, int32_t H, int32_t W);
+int swf_window_attention_bwd(const swf_attn_desc* desc, const swf_attn_params* p, const float* q, const float* k, const float* v,
+                             const float* gout, float* gq, float* gk, float* gv, const swf_attn_grads* gp,
+                             int32_t B, int32_t H, int32_t W, void* workspace, size_t workspace_bytes, swf_stream_t stream);
+/* one stream of AutoPathMLP.forward (a003:46-50): out = fc2(ELU(fc1(x))), x [tokens][channels] */
+size_t swf_mlp_bwd_workspace_bytes(int64_t tokens, int32_t channels, int32_t hidden);
+int swf_mlp_bwd(const swf_linear* fc1, const swf_linear* fc2, const float* x, const float* gout, float* gx,
+                const swf_linear_grad* gfc1, const swf_linear_grad* gfc2, int64_t tokens, int32_t channels, int32_t hidden,
+                void* workspace, size_t workspace_bytes, swf_stream_t stream);
+/* my_layer_norm (a004:54-72) */
+size_t swf_layernorm_bwd_workspace_bytes(int64_t tokens, int32_t C);
+int swf_layernorm_bwd(const swf_norm* ln, const float* x, const float* gout, float* gx, const swf_norm_grad* gp,
+                      int64_t tokens, int32_t C, void* workspace, size_t workspace_bytes, swf_stream_t stream);
+
 /* SelfAndCrossBlockPair.forward (a012_SelfAndCrossBlockPair.py:70-78): four BasicBlocks in the
  * order self/normal, self/shifted, cross/normal, cross/shifted (a009:90-109).  `desc` gives the
  * shared dims; shift/cross flags inside it are ignored.  px[4], py[4]. */

@@ -90,6 +90,12 @@ SIGNATURES = {
     "swf_basic_block_bwd_workspace_bytes": (_sz, [P(BlockDesc), _i32, _i32, _i32]),
     "swf_basic_block_bwd": (C.c_int, [P(BlockDesc), P(BlockStreamParams), P(BlockStreamParams), _vp, _vp, _vp, _vp, _vp, _vp,
                                       P(BlockStreamParams), P(BlockStreamParams), _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_window_attention_bwd_workspace_bytes": (_sz, [P(AttnDesc), _i32, _i32, _i32]),
+    "swf_window_attention_bwd": (C.c_int, [P(AttnDesc), P(AttnParams), _vp, _vp, _vp, _vp, _vp, _vp, _vp, P(AttnParams), _i32, _i32, _i32, _vp, _sz, _vp]),
+    "swf_mlp_bwd_workspace_bytes": (_sz, [_i64, _i32, _i32]),
+    "swf_mlp_bwd": (C.c_int, [P(Linear), P(Linear), _vp, _vp, _vp, P(Linear), P(Linear), _i64, _i32, _i32, _vp, _sz, _vp]),
+    "swf_layernorm_bwd_workspace_bytes": (_sz, [_i64, _i32]),
+    "swf_layernorm_bwd": (C.c_int, [P(Norm), _vp, _vp, _vp, P(Norm), _i64, _i32, _vp, _sz, _vp]),
     "swf_patch_layer_bwd_workspace_bytes": (_sz, [_i32] * 8),
     "swf_patch_layer_bwd": (C.c_int, [P(PatchParams), _vp, _vp, _vp, P(PatchParams), _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _sz, _vp]),
     "swf_reflect_pad_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, _vp]),

@@ -9,6 +9,18 @@ int basic_block_bwd(const swf_block_desc& d, const swf_block_stream_params* px, 
                     const float* y_in, const float* gx_out, const float* gy_out, float* gx_in, float* gy_in, const swf_block_stream_grads* gx,
                     const swf_block_stream_grads* gy, int B, int H, int W, void* workspace, size_t workspace_bytes, hipStream_t stream);
 
+// the inner modules on their own: WindowAttention (a001), one MLP stream (a003), one LayerNorm (a004)
+size_t window_attention_bwd_ws(const swf_attn_desc& d, int B, int H, int W);
+int window_attention_bwd(const swf_attn_desc& d, const swf_attn_params& p, const float* q_in, const float* k_in, const float* v_in, const float* gout,
+                         float* gq, float* gk, float* gv, const swf_attn_grads* gp, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                         hipStream_t stream);
+size_t mlp_bwd_ws(int64_t N, int C, int hid);
+int mlp_bwd(const swf_linear& fc1, const swf_linear& fc2, const float* x, const float* gout, float* gx, const swf_linear_grad* g1, const swf_linear_grad* g2,
+            int64_t N, int C, int hid, void* workspace, size_t workspace_bytes, hipStream_t stream);
+size_t layernorm_bwd_ws(int64_t N, int C);
+int layernorm_bwd(const swf_norm& ln, const float* x, const float* gout, float* gx, const swf_norm_grad* gp, int64_t N, int C, void* workspace,
+                  size_t workspace_bytes, hipStream_t stream);
+
 // PatchMergingAndLinearLayer (one stream; H x W = the layer's input map), reflect pad, elementwise add
 size_t patch_bwd_ws(int B, int H, int W, int Cin, int Cout, int mh, int mw, int encoder);
 int patch_bwd(const swf_patch_params& p, const float* in, const float* gout, float* gin, const swf_patch_grads* gp, int B, int H, int W, int Cin,

@@ -755,6 +755,91 @@ int basic_block_bwd(const swf_block_desc& d, const swf_block_stream_params* px, 
     return SWF_OK;
 }
 
+// ---- the inner modules on their own (a001 / a003 / a004 under autograd): WindowAttention, one MLP stream, one LayerNorm ---------------
+size_t window_attention_bwd_ws(const swf_attn_desc& d, int B, int H, int W) {
+    const int64_t N = (int64_t)B * H * W, C = d.channels, HD = (int64_t)d.heads * d.head_dim;
+    const int64_t nwin = (int64_t)B * (H / d.win_h) * (W / d.win_w), tsz = (int64_t)(2 * d.win_h - 1) * (2 * d.win_w - 1);
+    return carve_bytes({N * HD, N * HD, N * HD, N * HD, N * HD, N * HD, N * HD, N * HD, tree_rows(nwin * d.heads) * tsz}) +
+           carve_bytes({bwd_scratch_floats(N, std::max(C, HD), C)});
+}
+
+// WindowAttention.forward (a001:448-474) under autograd: out = proj(attention(q_in Wq, k_in Wk, v_in Wv)).  Q / K / V and the attention
+// output are recomputed in exact fp32; gq / gk / gv are the gradients of the three inputs (separate buffers: the caller adds them where
+// one tensor was passed more than once).
+int window_attention_bwd(const swf_attn_desc& d, const swf_attn_params& p, const float* q_in, const float* k_in, const float* v_in, const float* gout,
+                         float* gq, float* gk, float* gv, const swf_attn_grads* gp, int B, int H, int W, void* workspace, size_t workspace_bytes,
+                         hipStream_t st) {
+    const int64_t N = (int64_t)B * H * W;
+    const int C = d.channels, HD = d.heads * d.head_dim, wh = d.win_h, ww = d.win_w, tsz = (2 * wh - 1) * (2 * ww - 1);
+    const int64_t nwin = (int64_t)B * (H / wh) * (W / ww);
+    if (N > INT32_MAX / std::max(C, HD)) return fail(SWF_ERR_UNSUPPORTED, "window_attention_bwd: token count");
+    Carver ws(workspace, workspace_bytes);
+    float* Q = ws.floats(N * HD); float* K = ws.floats(N * HD); float* V = ws.floats(N * HD); float* O = ws.floats(N * HD);
+    float* dO = ws.floats(N * HD); float* dQ = ws.floats(N * HD); float* dK = ws.floats(N * HD); float* dV = ws.floats(N * HD);
+    float* dtab = ws.floats(tree_rows(nwin * d.heads) * tsz);
+    float* scratch = ws.floats(bwd_scratch_floats(N, std::max(C, HD), C));
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "window_attention_bwd workspace too small (need %zu B)", ws.used);
+    static const swf_attn_grads none{};
+    const swf_attn_grads& g = gp ? *gp : none;
+    GemmBatch gq3{};
+    gq3.p[0] = GemmProb{q_in, p.q.weight, p.q.bias, nullptr, Q};
+    gq3.p[1] = GemmProb{k_in, p.k.weight, p.k.bias, nullptr, K};
+    gq3.p[2] = GemmProb{v_in, p.v.weight, p.v.bias, nullptr, V};
+    SWF_TRY(launch_gemm_f32(gq3, 3, (int)N, HD, C, C, HD, 0, st));
+    AttnCoreBatch ac{};
+    ac.p[0] = AttnCoreProb{Q, K, V, O, p.bias_table};
+    SWF_TRY(launch_attn_core(ac, 1, HD, HD, HD, HD, B, H, W, wh, ww, d.heads, d.head_dim, d.shift, st));
+    SWF_TRY(dx(gout, p.proj.weight, dO, N, C, HD, 0, st));                                  // dO = gout . Wp
+    SWF_TRY(dw(gout, O, g.proj.weight, g.proj.bias, N, C, HD, scratch, st));
+    AttnBwdBatch ab{};
+    ab.p[0] = AttnBwdProb{Q, K, V, dO, dQ, dK, dV, p.bias_table, dtab};
+    SWF_TRY(launch_attn_bwd(ab, 1, HD, B, H, W, wh, ww, d.heads, d.head_dim, d.shift, st));
+    if (g.bias_table) SWF_TRY(reduce_rows(dtab, g.bias_table, (int64_t)tsz, nwin * d.heads, st));
+    SWF_TRY(dx(dQ, p.q.weight, gq, N, HD, C, 0, st));
+    SWF_TRY(dx(dK, p.k.weight, gk, N, HD, C, 0, st));
+    SWF_TRY(dx(dV, p.v.weight, gv, N, HD, C, 0, st));
+    SWF_TRY(dw(dQ, q_in, g.q.weight, g.q.bias, N, HD, C, scratch, st));
+    SWF_TRY(dw(dK, k_in, g.k.weight, g.k.bias, N, HD, C, scratch, st));
+    SWF_TRY(dw(dV, v_in, g.v.weight, g.v.bias, N, HD, C, scratch, st));
+    return SWF_OK;
+}
+
+size_t mlp_bwd_ws(int64_t N, int C, int hid) {
+    return carve_bytes({N * hid, N * hid}) + carve_bytes({bwd_scratch_floats(N, std::max(C, hid), C)});
+}
+
+// one stream of AutoPathMLP.forward (a003:46-50) under autograd: out = fc2(ELU(fc1(x)))
+int mlp_bwd(const swf_linear& fc1, const swf_linear& fc2, const float* x, const float* gout, float* gx, const swf_linear_grad* g1, const swf_linear_grad* g2,
+            int64_t N, int C, int hid, void* workspace, size_t workspace_bytes, hipStream_t st) {
+    if (N > INT32_MAX / std::max(C, hid)) return fail(SWF_ERR_UNSUPPORTED, "mlp_bwd: token count");
+    Carver ws(workspace, workspace_bytes);
+    float* h = ws.floats(N * hid); float* dh = ws.floats(N * hid);
+    float* scratch = ws.floats(bwd_scratch_floats(N, std::max(C, hid), C));
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "mlp_bwd workspace too small (need %zu B)", ws.used);
+    static const swf_linear_grad none{};
+    GemmBatch gb{};
+    gb.p[0] = GemmProb{x, fc1.weight, fc1.bias, nullptr, h};
+    SWF_TRY(launch_gemm_f32(gb, 1, (int)N, hid, C, C, hid, 1, st));                          // h = ELU(fc1 x)
+    SWF_TRY(dx(gout, fc2.weight, dh, N, C, hid, 0, st));
+    SWF_TRY(dw(gout, h, (g2 ? *g2 : none).weight, (g2 ? *g2 : none).bias, N, C, hid, scratch, st));
+    hipLaunchKernelGGL(elu_bwd_kernel, dim3((unsigned)cdiv64(N * hid, 256)), dim3(256), 0, st, dh, h, N * hid);
+    SWF_TRY(check_launch("elu_bwd"));
+    SWF_TRY(dx(dh, fc1.weight, gx, N, hid, C, 0, st));
+    SWF_TRY(dw(dh, x, (g1 ? *g1 : none).weight, (g1 ? *g1 : none).bias, N, hid, C, scratch, st));
+    return SWF_OK;
+}
+
+size_t layernorm_bwd_ws(int64_t N, int C) { return carve_bytes({bwd_scratch_floats(N, 1, C)}); }
+
+// my_layer_norm (a004:54-72) under autograd
+int layernorm_bwd(const swf_norm& ln, const float* x, const float* gout, float* gx, const swf_norm_grad* gp, int64_t N, int C, void* workspace,
+                  size_t workspace_bytes, hipStream_t st) {
+    Carver ws(workspace, workspace_bytes);
+    float* scratch = ws.floats(bwd_scratch_floats(N, 1, C));
+    if (!ws.ok()) return fail(SWF_ERR_WORKSPACE, "layernorm_bwd workspace too small (need %zu B)", ws.used);
+    return ln_bwd(x, ln.gamma, gout, nullptr, gx, gp ? gp->gamma : nullptr, gp ? gp->beta : nullptr, N, C, scratch, st);
+}
+
 // ---- PatchMergingAndLinearLayer backward (a011:244-264 under autograd), one stream, no window padding (the module-level layer) ----------
 size_t patch_bwd_ws(int B, int H, int W, int Cin, int Cout, int mh, int mw, int encoder) {
     const int64_t n = encoder ? (int64_t)B * (H / mh) * (W / mw) : (int64_t)B * H * W;   // merged tokens

@@ -1192,6 +1192,49 @@ int swf_basic_block_bwd(const swf_block_desc* desc, const swf_block_stream_param
     return basic_block_bwd(*desc, px, py, x_in, y_in, gx_out, gy_out, gx_in, gy_in, gpx, gpy, B, H, W, workspace, workspace_bytes, as_stream(stream));
 }
 
+size_t swf_window_attention_bwd_workspace_bytes(const swf_attn_desc* desc, int32_t B, int32_t H, int32_t W) {
+    if (!desc || B <= 0 || H <= 0 || W <= 0 || desc->win_h <= 0 || desc->win_w <= 0 || desc->channels <= 0 || desc->heads <= 0 || desc->head_dim <= 0) return 0;
+    return window_attention_bwd_ws(*desc, B, H, W);
+}
+
+int swf_window_attention_bwd(const swf_attn_desc* desc, const swf_attn_params* p, const float* q, const float* k, const float* v, const float* gout,
+                             float* gq, float* gk, float* gv, const swf_attn_grads* gp, int32_t B, int32_t H, int32_t W, void* workspace,
+                             size_t workspace_bytes, swf_stream_t stream) {
+    if (!desc || !p || !q || !k || !v || !gout || !gq || !gk || !gv) return fail(SWF_ERR_NULL, "window_attention_bwd: NULL argument");
+    if (!p->q.weight || !p->k.weight || !p->v.weight || !p->proj.weight || !p->bias_table) return fail(SWF_ERR_NULL, "window_attention_bwd: NULL parameter");
+    if (B <= 0 || H <= 0 || W <= 0 || desc->channels <= 0 || desc->heads <= 0 || desc->head_dim <= 0 || desc->win_h <= 0 || desc->win_w <= 0)
+        return fail(SWF_ERR_BAD_SHAPE, "window_attention_bwd: bad sizes");
+    if (H % desc->win_h || W % desc->win_w)
+        return fail(SWF_ERR_BAD_SHAPE, "window_attention_bwd: map %dx%d is not a multiple of the window %dx%d", H, W, desc->win_h, desc->win_w);
+    if (gq == gk || gq == gv || gk == gv) return fail(SWF_ERR_UNSUPPORTED, "window_attention_bwd: gq, gk, gv must be three buffers");
+    return window_attention_bwd(*desc, *p, q, k, v, gout, gq, gk, gv, gp, B, H, W, workspace, workspace_bytes, as_stream(stream));
+}
+
+size_t swf_mlp_bwd_workspace_bytes(int64_t tokens, int32_t channels, int32_t hidden) {
+    if (tokens <= 0 || channels <= 0 || hidden <= 0) return 0;
+    return mlp_bwd_ws(tokens, channels, hidden);
+}
+
+int swf_mlp_bwd(const swf_linear* fc1, const swf_linear* fc2, const float* x, const float* gout, float* gx, const swf_linear_grad* gfc1,
+                const swf_linear_grad* gfc2, int64_t tokens, int32_t channels, int32_t hidden, void* workspace, size_t workspace_bytes,
+                swf_stream_t stream) {
+    if (!fc1 || !fc2 || !fc1->weight || !fc2->weight || !x || !gout || !gx) return fail(SWF_ERR_NULL, "mlp_bwd: NULL argument");
+    if (tokens <= 0 || channels <= 0 || hidden <= 0) return fail(SWF_ERR_BAD_SHAPE, "mlp_bwd: bad sizes");
+    return mlp_bwd(*fc1, *fc2, x, gout, gx, gfc1, gfc2, tokens, channels, hidden, workspace, workspace_bytes, as_stream(stream));
+}
+
+size_t swf_layernorm_bwd_workspace_bytes(int64_t tokens, int32_t C) {
+    if (tokens <= 0 || C <= 0) return 0;
+    return layernorm_bwd_ws(tokens, C);
+}
+
+int swf_layernorm_bwd(const swf_norm* ln, const float* x, const float* gout, float* gx, const swf_norm_grad* gp, int64_t tokens, int32_t C,
+                      void* workspace, size_t workspace_bytes, swf_stream_t stream) {
+    if (!ln || !ln->gamma || !ln->beta || !x || !gout || !gx) return fail(SWF_ERR_NULL, "layernorm_bwd: NULL argument");
+    if (tokens <= 0 || C <= 0) return fail(SWF_ERR_BAD_SHAPE, "layernorm_bwd: bad sizes");
+    return layernorm_bwd(*ln, x, gout, gx, gp, tokens, C, workspace, workspace_bytes, as_stream(stream));
+}
+
 size_t swf_patch_layer_bwd_workspace_bytes(int32_t B, int32_t H, int32_t W, int32_t Cin, int32_t Cout, int32_t merge_h, int32_t merge_w, int32_t encoder) {
     if (B <= 0 || H <= 0 || W <= 0 || Cin <= 0 || Cout <= 0 || merge_h <= 0 || merge_w <= 0) return 0;
     return patch_bwd_ws(B, H, W, Cin, Cout, merge_h, merge_w, encoder);

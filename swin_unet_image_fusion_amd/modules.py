@@ -202,6 +202,15 @@ class WindowAttention(_FwdAlias, nn.Module):
             raise NotImplementedError("dropout > 0 in training mode is outside the forward-only HIP path")
 
     def forward(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+        """a001:448-474.  With torch.autograd recording the call is differentiable (swf_window_attention_bwd: exact fp32)."""
+        if _wants_grad(self, q, k, v):
+            self._check_dropout()
+            names = ("q_for_heads", "k_for_heads", "v_for_heads", "linear_projection")
+            prm = [t for n in names for t in (getattr(self, n).weight, getattr(self, n).bias)]
+            return _WindowAttentionFunction.apply(self, q, k, v, self.relative_position_bias_table, *prm)
+        return self._forward_nograd(q, k, v)
+
+    def _forward_nograd(self, q: Tensor, k: Tensor, v: Tensor) -> Tensor:
         _check_forward_only(self, q, k, v)
         self._check_dropout()
         if q.shape != k.shape or q.shape != v.shape:
@@ -221,6 +230,107 @@ class WindowAttention(_FwdAlias, nn.Module):
         L.check(lib.swf_window_attention_fwd_prec(C.byref(desc), _precision_code(self.precision), C.byref(prm), _ptr(qn), _ptr(kn),
                                                   _ptr(vn), None, _ptr(out), b, h, w, ws, wsn, _stream(q.device)))
         return _to_nchw(out)
+
+
+class _WindowAttentionFunction(torch.autograd.Function):
+    """WindowAttention.forward under torch.autograd: forward = the module's own forward (its precision tier), backward =
+    swf_window_attention_bwd.  q, k, v may be one tensor: autograd adds the three input gradients."""
+
+    @staticmethod
+    def forward(ctx, module, q, k, v, table, *params):
+        ctx.module = module
+        ctx.save_for_backward(q, k, v)
+        with torch.no_grad():
+            return module._forward_nograd(q.detach(), k.detach(), v.detach())
+
+    @staticmethod
+    def backward(ctx, g):
+        m = ctx.module
+        q, k, v = ctx.saved_tensors
+        b, c, h, w = q.shape
+        dev = q.device
+        with torch.no_grad():
+            qn = _to_nhwc(q)
+            kn = qn if k is q else _to_nhwc(k)
+            vn = kn if v is k else (qn if v is q else _to_nhwc(v))
+            gn = _to_nhwc(g.contiguous())
+            gq, gk, gv = torch.empty_like(qn), torch.empty_like(qn), torch.empty_like(qn)
+            new = lambda t: None if t is None else torch.empty(t.shape, dtype=torch.float32, device=dev)
+            lin = lambda wt, bs: L.Linear(wt.data_ptr(), None if bs is None else bs.data_ptr())
+            mods = (m.q_for_heads, m.k_for_heads, m.v_for_heads, m.linear_projection)
+            gw = [new(md.weight) for md in mods]
+            gb = [new(md.bias) for md in mods]
+            gt = new(m.relative_position_bias_table)
+            grads = L.AttnParams(lin(gw[0], gb[0]), lin(gw[1], gb[1]), lin(gw[2], gb[2]), lin(gw[3], gb[3]), gt.data_ptr())
+            lib, desc, prm = L.lib(), m._desc(), m._params()
+            ws, wsn = _workspace(lib.swf_window_attention_bwd_workspace_bytes(C.byref(desc), b, h, w), dev)
+            L.check(lib.swf_window_attention_bwd(C.byref(desc), C.byref(prm), _ptr(qn), _ptr(kn), _ptr(vn), _ptr(gn), _ptr(gq), _ptr(gk), _ptr(gv),
+                                                 C.byref(grads), b, h, w, ws, wsn, _stream(dev)))
+            flat = [t for pair in zip(gw, gb) for t in pair]
+            return (None, _to_nchw(gq), _to_nchw(gk), _to_nchw(gv), gt, *flat)
+
+
+class _MlpFunction(torch.autograd.Function):
+    """One stream of AutoPathMLP.forward (a003:46-50) under torch.autograd: forward swf_mlp_fwd, backward swf_mlp_bwd."""
+
+    @staticmethod
+    def forward(ctx, module, s, x, w1, b1, w2, b2):
+        ctx.module, ctx.s = module, s
+        ctx.save_for_backward(x)
+        with torch.no_grad():
+            return module._one_nograd(x.detach(), s)
+
+    @staticmethod
+    def backward(ctx, g):
+        m, s = ctx.module, ctx.s
+        (x,) = ctx.saved_tensors
+        b, c, h, w = x.shape
+        dev = x.device
+        c1, c2 = getattr(m, f"mlp_{s}_1"), getattr(m, f"mlp_{s}_2")
+        with torch.no_grad():
+            xn, gn = _to_nhwc(x), _to_nhwc(g.contiguous())
+            gx = torch.empty_like(xn)
+            new = lambda t: None if t is None else torch.empty(t.shape, dtype=torch.float32, device=dev)
+            g1w, g1b, g2w, g2b = new(c1.weight), new(c1.bias), new(c2.weight), new(c2.bias)
+            ptr = lambda t: None if t is None else t.data_ptr()
+            f1, f2 = _lin(c1), _lin(c2)
+            gf1, gf2 = L.Linear(ptr(g1w), ptr(g1b)), L.Linear(ptr(g2w), ptr(g2b))
+            lib, n = L.lib(), b * h * w
+            ws, wsn = _workspace(lib.swf_mlp_bwd_workspace_bytes(n, c, m.hidden_dims), dev)
+            L.check(lib.swf_mlp_bwd(C.byref(f1), C.byref(f2), _ptr(xn), _ptr(gn), _ptr(gx), C.byref(gf1), C.byref(gf2), n, c, m.hidden_dims,
+                                    ws, wsn, _stream(dev)))
+            return None, None, _to_nchw(gx), g1w, g1b, g2w, g2b
+
+
+class _LayerNormFunction(torch.autograd.Function):
+    """my_layer_norm (a004:54-72: LayerNorm over the channels of an NCHW map) under torch.autograd."""
+
+    @staticmethod
+    def forward(ctx, ln, x, gamma, beta):
+        ctx.ln = ln
+        ctx.save_for_backward(x)
+        b, c, h, w = x.shape
+        xn = _to_nhwc(x.detach())
+        out = torch.empty_like(xn)
+        nrm = _norm(ln)
+        L.check(L.lib().swf_layernorm_fwd(C.byref(nrm), _ptr(xn), _ptr(out), b * h * w, c, 0, _stream(x.device)))
+        return _to_nchw(out)
+
+    @staticmethod
+    def backward(ctx, g):
+        ln = ctx.ln
+        (x,) = ctx.saved_tensors
+        b, c, h, w = x.shape
+        dev = x.device
+        with torch.no_grad():
+            xn, gn = _to_nhwc(x), _to_nhwc(g.contiguous())
+            gx = torch.empty_like(xn)
+            gg, gb = torch.empty_like(ln.weight), torch.empty_like(ln.bias)
+            nrm, grads = _norm(ln), L.Norm(gg.data_ptr(), gb.data_ptr())
+            lib, n = L.lib(), b * h * w
+            ws, wsn = _workspace(lib.swf_layernorm_bwd_workspace_bytes(n, c), dev)
+            L.check(lib.swf_layernorm_bwd(C.byref(nrm), _ptr(xn), _ptr(gn), _ptr(gx), C.byref(grads), n, c, ws, wsn, _stream(dev)))
+            return None, _to_nchw(gx), gg, gb
 
 
 # ----------------------------------------------------------------------------------------------
@@ -276,8 +386,30 @@ class AutoPathMLP(_FwdAlias, nn.Module):
         p.fc1, p.fc2 = _lin(getattr(self, f"mlp_{s}_1")), _lin(getattr(self, f"mlp_{s}_2"))
         return p
 
-    def forward(self, x, y):
-        """a003:46-50 through swf_mlp_fwd: both streams in one call (one launch of the fused kernel's MLP half at level-0 width)."""
+    def _one_nograd(self, x: Tensor, s: str) -> Tensor:
+        b, c, h, w = x.shape
+        xn = _to_nhwc(x)
+        ox = torch.empty_like(xn)
+        lib, prec, n = L.lib(), _precision_code(self.precision), b * h * w
+        px = self._params(s)
+        ws, wsn = _workspace(lib.swf_mlp_workspace_bytes(prec, n, c, self.hidden_dims), x.device)
+        L.check(lib.swf_mlp_fwd(prec, C.byref(px), None, _ptr(xn), None, _ptr(ox), None, n, c, self.hidden_dims, ws, wsn, _stream(x.device)))
+        return _to_nchw(ox)
+
+    def _one_grad(self, x: Tensor, s: str) -> Tensor:
+        c1, c2 = getattr(self, f"mlp_{s}_1"), getattr(self, f"mlp_{s}_2")
+        return _MlpFunction.apply(self, s, x, c1.weight, c1.bias, c2.weight, c2.bias)
+
+    def forward(self, x, y=None):
+        """a003:46-50 through swf_mlp_fwd: both streams in one call (one launch of the fused kernel's MLP half at level-0 width).  With
+        torch.autograd recording each stream is a differentiable call (swf_mlp_bwd: exact fp32)."""
+        if _wants_grad(self, x, y):
+            _require_elu(self.activation_func)
+            if self.training and self.drop_ratio:
+                raise NotImplementedError("dropout > 0 in training mode is outside the HIP path")
+            if self.use_dual_path or y is not None:
+                return self._one_grad(x, "x"), self._one_grad(y, "y")
+            return self._one_grad(x, "x")
         _check_forward_only(self, x, y)
         _require_elu(self.activation_func)
         if self.training and self.drop_ratio:
@@ -313,10 +445,20 @@ class AddAndLayerNormWithOtherModule(_FwdAlias, nn.Module):
         if use_dual_path:
             self.norm_layer_2 = nn.LayerNorm(normalized_shape=normalized_shape)
 
-    def forward(self, x, y):
-        _check_forward_only(self, x, y)
+    def forward(self, x, y=None):
         om = self.other_module
         dual = self.use_dual_path or y is not None
+        if _wants_grad(self, x, y):
+            # under torch.autograd the wrapper is composed of differentiable calls: LayerNorm, the other module, the residual add
+            if not isinstance(om, (AutoPathWinAtt, AutoPathMLP)):
+                raise NotImplementedError("other_module must be AutoPathWinAtt or AutoPathMLP of this package")
+            nx = _LayerNormFunction.apply(self.norm_layer_1, x, self.norm_layer_1.weight, self.norm_layer_1.bias)
+            if not dual:
+                return _AddFunction.apply(x, om(nx, None) if isinstance(om, AutoPathMLP) else om(nx, nx))
+            ny = _LayerNormFunction.apply(self.norm_layer_2, y, self.norm_layer_2.weight, self.norm_layer_2.bias)
+            ox, oy = om(nx, ny)
+            return _AddFunction.apply(x, ox), _AddFunction.apply(y, oy)
+        _check_forward_only(self, x, y)
         b, c, h, w = x.shape
         xn, yn = _to_nhwc(x), (_to_nhwc(y) if dual else None)
         ox = torch.empty_like(xn)

@@ -262,3 +262,98 @@ def test_head_batch_statistics_match_torch():
     bn = m.final_layer[1]
     assert torch.allclose(bn.running_mean.cpu(), rm, rtol=1e-5, atol=1e-6) and torch.allclose(bn.running_var.cpu(), rv, rtol=1e-5, atol=1e-6)
     assert torch.allclose(bn.running_mean.cpu(), 0.9 * rm0 + 0.1 * mean, rtol=1e-5, atol=1e-6)
+
+
+_WA_CASES = [  # C, heads, d, win, (B,H,W), shift, mode (self: q=k=v one tensor; cross: k=v the other stream; mixed: three tensors), qkv bias
+    (24, 8, 3, 8, (1, 16, 16), True, "self", True),
+    (24, 8, 3, 8, (2, 8, 16), False, "cross", True),
+    (12, 4, 3, 7, (1, 14, 7), True, "cross", True),
+    (16, 2, 5, 4, (1, 8, 8), True, "mixed", False),          # heads * d != C, no q/k/v bias
+    (8, 2, 4, 16, (1, 16, 16), True, "self", True),          # 16x16 window: the recompute kernel
+]
+
+
+@pytest.mark.parametrize("case", _WA_CASES, ids=[f"C{c[0]}_w{c[3]}_s{int(c[5])}_{c[6]}" for c in _WA_CASES])
+def test_window_attention_backward_vs_autograd_of_the_oracle(case):
+    """WindowAttention on its own (a001:448-474, the drop-in the north star names) under torch.autograd: input gradients — summed by
+    autograd where one tensor is passed as several of q, k, v — and every parameter gradient against autograd of the oracle."""
+    from swin_unet_image_fusion_amd import WindowAttention
+    c, heads, d, win, (b, h, w), shift, mode, bias = case
+    m = WindowAttention(c, heads, d, (win, win), shift, mode != "self", bias, 0.0, 0.0).eval()
+    load_recipe_into(m, seed=21, flavor="stress")
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    a, bt, ct = (G.randn((b, c, h, w), 700 + i).requires_grad_(True) for i in range(3))
+    pick = {"self": (a, a, a), "cross": (a, bt, bt), "mixed": (a, bt, ct)}[mode]
+    wgt = G.randn((b, c, h, w), 710)
+    out = O.window_attention(sd, "", *pick, num_heads=heads, dims_per_head=d, window_size=(win, win), use_cyclic_shift=shift)
+    (out * wgt).sum().backward()
+    m.to(DEV)
+    ag, bg, cg = (t.detach().to(DEV).requires_grad_(True) for t in (a, bt, ct))
+    pickg = {"self": (ag, ag, ag), "cross": (ag, bg, bg), "mixed": (ag, bg, cg)}[mode]
+    outg = m(*pickg)
+    assert outg.requires_grad
+    assert float((outg.detach().cpu() - out.detach()).abs().max() / out.detach().abs().max()) <= 2e-3
+    (outg * wgt.to(DEV)).sum().backward()
+    rel = lambda got, ref: float((got.detach().cpu().double() - ref.detach().double()).norm() / ref.detach().double().norm().clamp_min(1e-30))
+    used = {"self": [(ag, a)], "cross": [(ag, a), (bg, bt)], "mixed": [(ag, a), (bg, bt), (cg, ct)]}[mode]
+    for got, ref in used:
+        assert rel(got.grad, ref.grad) <= 2e-3, rel(got.grad, ref.grad)
+    # (the key bias has NO gradient mathematically — a shift of every key by b_k moves all scores of a query by the same q.b_k —, so both
+    #  sides hold rounding noise there: errors are measured against the largest gradient of the module, not against each tensor's own size)
+    gmax = max(float(v.grad.abs().max()) for v in sd.values())
+    for k, p in m.named_parameters():
+        assert p.grad is not None and sd[k].grad is not None, k
+        err = float((p.grad.detach().cpu().double() - sd[k].grad.double()).abs().max()) / max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
+        assert err <= 5e-3, (k, err)
+
+
+@pytest.mark.parametrize("dual", [True, False], ids=["dual", "single"])
+def test_inner_modules_backward_compose_like_the_block(dual):
+    """The reference's BasicBlock assembled from this package's inner modules (a005:70-82: AddAndLayerNorm around AutoPathWinAtt, then
+    around AutoPathMLP) under torch.autograd — the caller that swaps only a001-a004: gradients of both inputs and of every parameter
+    equal autograd of the oracle's basic_block, and equal the fused block's own backward."""
+    from swin_unet_image_fusion_amd import AddAndLayerNormWithOtherModule
+    c, heads, d, win, hid, (b, h, w) = 24, 8, 3, 8, 96, (1, 16, 16)
+    m = BasicBlock(c, heads, d, (win, win), True, dual, dual, True, 0.0, 0.0, hid, nn.ELU(inplace=True), 0.0).eval()
+    load_recipe_into(m, seed=5, flavor="stress")
+    sd = {k: v.detach().clone().requires_grad_(True) for k, v in m.state_dict().items()}
+    x, y = G.randn((b, c, h, w), 801).requires_grad_(True), G.randn((b, c, h, w), 802).requires_grad_(True)
+    wx, wy = G.randn((b, c, h, w), 803), G.randn((b, c, h, w), 804)
+    if dual:
+        ox, oy = O.basic_block(sd, "", x, y, cross=True, shift=True, num_heads=heads, dims_per_head=d, window_size=(win, win))
+        ((ox * wx).sum() + (oy * wy).sum()).backward()
+    else:   # single path (a005 with use_dual_path False): the oracle's pieces by hand
+        import torch.nn.functional as F
+        n1 = O.layer_norm_channels(x, sd["stage_1.norm_layer_1.weight"], sd["stage_1.norm_layer_1.bias"])
+        a1 = O.window_attention(sd, "auto_path_win_att.window_attention_x.", n1, n1, n1, num_heads=heads, dims_per_head=d,
+                                window_size=(win, win), use_cyclic_shift=True)
+        x1r = x + a1
+        n2 = O.layer_norm_channels(x1r, sd["stage_2.norm_layer_1.weight"], sd["stage_2.norm_layer_1.bias"])
+        hdn = F.elu(F.conv2d(n2, sd["auto_path_mlp.mlp_x_1.weight"], sd["auto_path_mlp.mlp_x_1.bias"]))
+        ox = x1r + F.conv2d(hdn, sd["auto_path_mlp.mlp_x_2.weight"], sd["auto_path_mlp.mlp_x_2.bias"])
+        (ox * wx).sum().backward()
+    m.to(DEV)
+    xg, yg = x.detach().to(DEV).requires_grad_(True), y.detach().to(DEV).requires_grad_(True)
+    assert isinstance(m.stage_1, AddAndLayerNormWithOtherModule)
+    rel = lambda got, ref: float((got.detach().cpu().double() - ref.detach().double()).norm() / ref.detach().double().norm().clamp_min(1e-30))
+    if dual:
+        x1, y1 = m.stage_1(xg, yg)
+        x2, y2 = m.stage_2(x1, y1)
+        assert x2.requires_grad and y2.requires_grad
+        ((x2 * wx.to(DEV)).sum() + (y2 * wy.to(DEV)).sum()).backward()
+        assert rel(xg.grad, x.grad) <= 2e-3 and rel(yg.grad, y.grad) <= 2e-3
+    else:
+        x2 = m.stage_2(m.stage_1(xg))
+        assert x2.requires_grad
+        (x2 * wx.to(DEV)).sum().backward()
+        assert rel(xg.grad, x.grad) <= 2e-3
+    seen = 0
+    gmax = max(float(v.grad.abs().max()) for v in sd.values() if v.grad is not None)
+    for k, p in m.named_parameters():
+        if sd[k].grad is None:
+            continue
+        assert p.grad is not None, k
+        err = float((p.grad.detach().cpu().double() - sd[k].grad.double()).abs().max()) / max(float(sd[k].grad.abs().max()), 1e-3 * gmax)
+        assert err <= 5e-3, (k, err)
+        seen += 1
+    assert seen >= (26 if dual else 13)
